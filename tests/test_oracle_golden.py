@@ -1,0 +1,106 @@
+"""CPU: the oracle against every fixture the reference's own tests hold for the path
+(SURVEY 8c), minted by tests/golden/make_golden.py from the reference's torch helpers."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def test_expf_accuracy():
+    x = np.concatenate([np.linspace(-86, 88, 20001), np.linspace(-8, 0.5, 20001)]).astype(np.float32)
+    got = oracle.expf(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 2.5e-7     # <= 2 ulp of f32
+
+
+def test_find_tile_start_and_end_known_answer(golden):
+    g = golden["find_tile_start_and_end"]          # reference tests :19-42, exact ints
+    ts, te = oracle.find_tile_start_and_end(np.array(g["keys"], np.int64), g["n_tiles"])
+    assert ts.tolist() == g["start"]
+    assert te.tolist() == g["end"]
+
+
+def test_rotation_matrix_from_quaternion(golden):
+    g = golden["quaternion_to_rotation"]           # GaussianPoint3D_test.py:56-67, atol 1e-2
+    R = oracle.rotation_matrix_from_quaternion(g["q_xyzw"])
+    assert np.allclose(R, np.array(g["R"]), atol=1e-5)
+    from scipy.spatial.transform import Rotation
+    assert np.allclose(R, Rotation.from_quat(g["q_xyzw"]).as_matrix(), atol=g["atol"])
+
+
+def test_project_to_camera_covariance(golden):
+    g = golden["project_to_camera_covariance"]     # GaussianPoint3D_test.py:12-54, rtol 1e-2
+    cov = oracle.project_to_camera_covariance(g["q_xyzw"], g["log_s"], np.eye(4), g["camera_intrinsics"], g["xyz"])
+    assert np.allclose(cov, np.array(g["cov"]), rtol=g["rtol"])
+
+
+def test_inverse_se3_qt(golden):
+    g = golden["inverse_SE3_qt"]                   # utils.py:426-432 outputs (float64) vs f32 oracle
+    qi, ti = oracle.inverse_se3_qt(g["q"], g["t"])
+    assert np.allclose(qi, np.array(g["q_inv"]), atol=1e-6)
+    assert np.allclose(ti, np.array(g["t_inv"]), atol=1e-6)
+
+
+def test_spherical_harmonics(golden):
+    g = golden["spherical_harmonics"]              # utils.py:635-657
+    for d, sh in zip(g["xyz"], g["sh16"]):
+        assert np.allclose(oracle.spherical_harmonics(d), np.array(sh), atol=2e-6)
+
+
+def _normalized_2d(xy, mean, cov):
+    """get_point_probability_density_from_2d_gaussian_normalized / grad_..._2d_normalized,
+    utils.py:240-254, 309-328 (un-blurred covariance; what the reference's single-point test uses)."""
+    d = xy - mean
+    inv = np.linalg.inv(cov)
+    p = np.exp(-0.5 * d @ inv @ d)
+    return p, p * (inv @ d), 0.5 * p * (inv @ np.outer(d, d) @ inv)
+
+
+def test_single_point_alpha_and_jacobians(golden):
+    """reference tests :353-548: alpha at pixel (3,3) and d alpha / d(xyz, q, s, opacity)."""
+    g = golden["single_point"]
+    T = np.array(g["T_camera_pointcloud"], np.float32)
+    Km = np.array(g["camera_intrinsics"], np.float32)
+    xyz = np.array(g["xyz"], np.float32)
+    feat = np.array(g["features"], np.float32)
+    q, s, opacity_logit = feat[:4], feat[4:7], feat[7]
+    pcam = (T @ np.append(xyz, 1.0).astype(np.float32))[:3]
+    uv = (Km @ pcam)[:2] / pcam[2]
+    cov = oracle.project_to_camera_covariance(q, s, T, Km, pcam).astype(np.float64)
+    xy = np.array(g["pixel_uv"], np.float64) + 0.5
+    p, dp_dmean, dp_dcov = _normalized_2d(xy, uv.astype(np.float64), cov)
+    opacity = 1.0 / (1.0 + float(oracle.expf(np.float32(-opacity_logit))))
+    alpha = p * opacity
+    tol = g["tolerance"]
+    assert abs(alpha - g["alpha"]) < tol["alpha_atol"]
+    # chain exactly as the reference's single_point_alpha_backward does (alpha_grad = 1)
+    J_uv = oracle.project_to_camera_position_jacobian(xyz, T, Km).astype(np.float64)
+    dSq, dSs = oracle.project_to_camera_covariance_jacobian(q, s, T, Km, pcam)
+    gaussian_alpha_grad = opacity
+    grad_xyz = gaussian_alpha_grad * dp_dmean @ J_uv
+    flat = np.array([dp_dcov[0, 0], dp_dcov[0, 1], dp_dcov[1, 0], dp_dcov[1, 1]])
+    grad_q = gaussian_alpha_grad * flat @ dSq.astype(np.float64)
+    grad_s = gaussian_alpha_grad * flat @ dSs.astype(np.float64)
+    grad_opacity = p * (1 - opacity) * opacity
+    assert np.allclose(grad_xyz, g["grad_xyz"], atol=tol["grad_xyz_atol"])
+    got = np.concatenate([grad_q, grad_s, [grad_opacity]])
+    assert np.allclose(got, g["grad_features_0_8"], atol=tol["grad_features_atol"])
+
+
+def test_feature_row_layout():
+    """reference tests :54-104: [0:4] q, [4:7] log-scale, [7] opacity logit, [8:24]/[24:40]/[40:56] SH.
+    A one-point scene: colour must come from exactly those slices."""
+    feat = np.zeros((1, 56), np.float32)
+    feat[0, :4] = [0, 0, 0, 2.0]          # un-normalised on purpose
+    feat[0, 4:7] = np.log(0.05)
+    feat[0, 7] = 3.0
+    feat[0, 8], feat[0, 24], feat[0, 40] = 1.0 / 0.28209479, -1.0 / 0.28209479, 0.0
+    pc = np.array([[0.0, 0.0, 4.0]], np.float32)
+    Km = np.array([[20, 0, 16], [0, 20, 16], [0, 0, 1]], np.float32)
+    f, feat_after = oracle.forward(pc, feat, [0], [0], [[0, 0, 0, 1]], [[0, 0, 0]], Km, 32, 32)
+    assert f.M == 1
+    assert np.allclose(feat_after[0, :4], [0, 0, 0, 1])                      # RAST:264-266 write-back
+    sig = lambda x: 1 / (1 + np.exp(-x))
+    assert np.allclose(f.point_color[0], [sig(1.0), sig(-1.0), sig(0.0)], atol=1e-6)
+    assert np.allclose(f.point_alpha_after_activation[0], sig(3.0), atol=1e-6)
+    assert np.allclose(f.point_uv[0], [16, 16])
