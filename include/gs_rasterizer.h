@@ -1,0 +1,180 @@
+/*
+ * gs_rasterizer.h -- C ABI of libgsrast.so, the MI355X (gfx950) drop-in for the
+ * rasterisation hot path of Wenri/taichi_3d_gaussian_splatting.
+ *
+ * The entry points are what the reference's Python operator would bind in place of
+ * its Taichi kernels; each one names the reference interface it replaces
+ * (paths under the reference repo, RAST = taichi_3d_gaussian_splatting/
+ * GaussianPointCloudRasterisation.py).  Plain C, no torch types: every pointer
+ * marked "device" is a HIP device pointer on the context's GPU, owned by the caller
+ * unless stated otherwise; the library never frees caller memory.  All functions
+ * return 0 on success and a negative gs_status otherwise, never throw, and set a
+ * thread-local message readable through gs_last_error().
+ *
+ * Threading: a gs_ctx may be used from any host thread, one call at a time
+ * (PyTorch calls forward on the main thread and backward on an autograd worker).
+ * All work of one ctx must be issued on one HIP stream at a time (buffers are
+ * recycled in stream order).
+ */
+#ifndef GS_RASTERIZER_H
+#define GS_RASTERIZER_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+#define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
+#define GS_FEATURES 56          /* RAST:208-236 row layout */
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARGUMENT = -1,   /* the reference's Python asserts / Taichi TypeErrors (RAST:1193-1194) */
+    GS_ERR_HIP = -2,                /* a HIP runtime call failed; message carries hipGetErrorString */
+    GS_ERR_OUT_OF_MEMORY = -3,
+    GS_ERR_STATE = -4               /* e.g. backward on a frame that was not kept */
+} gs_status;
+
+typedef struct gs_ctx gs_ctx;       /* one per operator instance per device (RAST:819-826) */
+typedef struct gs_frame gs_frame;   /* what RAST:998-1021 ctx.save_for_backward keeps alive */
+typedef void* gs_stream;            /* hipStream_t; NULL = the legacy default stream */
+
+/* GaussianPointCloudRasterisationConfig, RAST:776-786 (same defaults) */
+typedef struct gs_config {
+    float   near_plane;                      /* 0.8   */
+    float   far_plane;                       /* 1000  */
+    float   depth_to_sort_key_scale;         /* 100   */
+    int32_t rgb_only;                        /* 0     */
+    float   grad_color_factor;               /* 5     */
+    float   grad_high_order_color_factor;    /* 1     */
+    float   grad_s_factor;                   /* 0.5   */
+    float   grad_q_factor;                   /* 1     */
+    float   grad_alpha_factor;               /* 20    */
+} gs_config;
+
+/* The point-cloud half of GaussianPointCloudRasterisationInput, RAST:788-804. */
+typedef struct gs_scene {
+    const float*   point_cloud;             /* device (N,3) f32 */
+    float*         point_cloud_features;    /* device (N,56) f32; [:,0:4] is normalised IN PLACE (RAST:264-266) */
+    const int8_t*  point_invalid_mask;      /* device (N) i8, 1 = skip */
+    const int32_t* point_object_id;         /* device (N) i32 in [0, n_objects) */
+    int64_t        n_points;                /* N */
+} gs_scene;
+
+/* The camera half: CameraInfo (Camera.py:6-11) + the pose rows, RAST:799-803. */
+typedef struct gs_camera {
+    const float* q_pointcloud_camera;       /* device (n_objects,4) xyzw */
+    const float* t_pointcloud_camera;       /* device (n_objects,3) */
+    int32_t      n_objects;
+    const float* camera_intrinsics;         /* device (3,3) row-major */
+    int32_t      camera_height;             /* multiples of 16 (RAST:1193-1194) */
+    int32_t      camera_width;
+} gs_camera;
+
+/* Image-sized outputs of the blend kernel, RAST:967-976.  With rgb_only only
+ * rasterized_image is written (RAST:478-484) and the others may be NULL. */
+typedef struct gs_forward_out {
+    float*   rasterized_image;                       /* device (H,W,3) f32 */
+    float*   rasterized_depth;                       /* device (H,W) f32 */
+    float*   pixel_accumulated_alpha;                /* device (H,W) f32 */
+    int32_t* pixel_offset_of_last_effective_point;   /* device (H,W) i32 */
+    int32_t* pixel_valid_point_count;                /* device (H,W) i32 */
+} gs_forward_out;
+
+/* Data-dependent sizes of a frame (the reference learns them through two
+ * device->host syncs, RAST:870 and RAST:916-931; here it is one). */
+typedef struct gs_frame_info {
+    int64_t n_points;               /* N */
+    int64_t n_points_in_camera;     /* M */
+    int64_t n_keys;                 /* K = sum of num_overlap_tiles */
+    int32_t n_tiles;                /* (W/16)*(H/16) */
+    int32_t camera_height, camera_width;
+    int32_t sort_key_bits;          /* significant bits actually radix-sorted */
+    int32_t kept_for_backward;
+} gs_frame_info;
+
+/* Outputs of backward, RAST:1051-1067 + RAST:1127-1140.  The first two are
+ * mandatory; every other pointer may be NULL (need_extra_info = false).
+ * All N-row arrays are fully written (rows outside the frustum = 0). */
+typedef struct gs_backward_out {
+    float*   grad_pointcloud;                   /* device (N,3)  */
+    float*   grad_pointcloud_features;          /* device (N,56) band-masked and factor-scaled (RAST:1102-1125) */
+    float*   grad_viewspace;                    /* device (N,2)  */
+    float*   magnitude_grad_viewspace;          /* device (N)    */
+    float*   magnitude_grad_viewspace_on_image; /* device (H,W,2) */
+    int32_t* num_affected_pixels;               /* device (M)    */
+    /* BackwardValidPointHookInput gathers (RAST:1128-1140), written directly: */
+    float*   hook_grad_point_in_camera;         /* device (M,3)  */
+    float*   hook_grad_pointfeatures_in_camera; /* device (M,56) */
+    float*   hook_grad_viewspace;               /* device (M,2)  */
+    float*   hook_magnitude_grad_viewspace;     /* device (M)    */
+} gs_backward_out;
+
+/* Intermediates a frame can copy out, in the reference's layouts (saved tensors
+ * RAST:998-1019 and the locals of RAST:873-964). */
+typedef enum gs_export {
+    GS_X_POINT_ID_IN_CAMERA_LIST = 0,   /* (M) i32 */
+    GS_X_POINT_UV = 1,                  /* (M,2) f32 */
+    GS_X_POINT_IN_CAMERA = 2,           /* (M,3) f32 */
+    GS_X_POINT_UV_CONIC_AND_RESCALE = 3,/* (M,4) f32 */
+    GS_X_POINT_ALPHA_AFTER_ACTIVATION = 4, /* (M) f32 */
+    GS_X_POINT_COLOR = 5,               /* (M,3) f32 */
+    GS_X_POINT_RADII = 6,               /* (M) f32 */
+    GS_X_NUM_OVERLAP_TILES = 7,         /* (M) i32 */
+    GS_X_ACCUMULATED_NUM_OVERLAP_TILES = 8, /* (M) i64, exclusive */
+    GS_X_SORT_KEY = 9,                  /* (K) i64 sorted: (tile_id << 32) + i32(depth*scale) */
+    GS_X_POINT_OFFSET_WITH_SORT_KEY = 10, /* (K) i32 sorted */
+    GS_X_TILE_POINTS_START = 11,        /* (T) i32 */
+    GS_X_TILE_POINTS_END = 12,          /* (T) i32 */
+    GS_X_POINT_DEPTH = 13,              /* (M) f32 = point_in_camera[:,2] */
+    GS_X_POINT_IN_CAMERA_MASK = 14,     /* (N) i8 */
+    GS_X_COUNT_
+} gs_export;
+
+int gs_abi_version(void);
+const char* gs_last_error(void);
+
+/* Replaces ti.init + module construction (GaussianPointTrainer.py:124, RAST:819-826). */
+int gs_create(int32_t device, gs_ctx** out);
+int gs_destroy(gs_ctx* ctx);
+
+/* Replaces _module_function.forward, RAST:830-1023 (kernels RAST:31-485).
+ * keep_for_backward != 0: *frame_out receives a handle that must be passed to
+ * gs_backward and/or gs_frame_release; 0: nothing is kept (torch.no_grad path,
+ * benchmark/inference_benchmark.py:110-156) and *frame_out still receives a handle
+ * valid for gs_frame_get_info/gs_frame_export until the next call on this ctx.
+ * When K == 0 the outputs are zero-filled (the reference leaves torch.empty
+ * garbage, RAST:967-980). */
+int gs_forward(gs_ctx* ctx, const gs_scene* scene, const gs_camera* camera, const gs_config* config,
+               const gs_forward_out* out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
+
+int gs_frame_get_info(const gs_frame* frame, gs_frame_info* info);
+
+/* Element count of an export (so the caller can size dst). */
+int64_t gs_frame_export_count(const gs_frame* frame, gs_export what);
+int gs_frame_export(const gs_frame* frame, gs_export what, void* dst_device, gs_stream stream);
+
+/* Replaces _module_function.backward, RAST:1025-1163 (kernel RAST:488-772 and the
+ * torch post-processing RAST:1102-1140).  pixel_accumulated_alpha and
+ * pixel_offset_of_last_effective_point are the forward's outputs (saved tensors
+ * RAST:1006-1007).  grad_rasterized_image is (H,W,3) contiguous. */
+int gs_backward(gs_ctx* ctx, gs_frame* frame, const gs_scene* scene, const gs_camera* camera,
+                const gs_config* config, const float* grad_rasterized_image,
+                const float* pixel_accumulated_alpha, const int32_t* pixel_offset_of_last_effective_point,
+                int32_t color_max_sh_band, const gs_backward_out* out, gs_stream stream);
+
+int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
+
+/* Bytes of device memory the context currently owns (arena + frames). */
+int64_t gs_ctx_device_bytes(const gs_ctx* ctx);
+
+/* Time spent in the last forward/backward's dominant kernels is measured by the
+ * caller with HIP events on `stream`; this returns the names of the kernels one
+ * forward+backward launches, for profile post-processing. */
+const char* gs_kernel_names(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,296 @@
+"""GaussianPointCloudRasterisation -- drop-in for the reference operator
+(taichi_3d_gaussian_splatting/GaussianPointCloudRasterisation.py:775-1204) backed by
+libgsrast.so (hand-written HIP for MI355X / gfx950) through its C ABI.
+
+Same class, nested dataclass names, field order, forward() contract and backward-hook
+payload as the reference.  The Python side only validates arguments, allocates the output
+tensors, keeps the opaque frame handle alive between forward and backward and dispatches
+the hook; all arithmetic happens in the library.  There is no fallback path.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from . import _native
+from .Camera import CameraInfo
+
+TILE_WIDTH = 16
+TILE_HEIGHT = 16
+
+try:  # the reference mixes in dataclass_wizard.YAMLWizard (RAST:777); optional here
+    from dataclass_wizard import YAMLWizard as _ConfigBase
+except Exception:  # pragma: no cover - not installed in the build image
+    class _ConfigBase:
+        pass
+
+_TORCH_DTYPES = {"float32": torch.float32, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _require(t: torch.Tensor, name: str, dtype, shape_tail, device=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a GPU (cuda/hip device), got {t.device}")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} must have shape (*, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}")
+
+
+class _Frame:
+    """Owner of a gs_frame handle: what ctx.save_for_backward keeps in the reference (RAST:998-1021)."""
+
+    def __init__(self, ctx_handle, handle, device):
+        self._ctx, self._h, self.device = ctx_handle, handle, device
+        info = _native.GsFrameInfo()
+        _native.check(_native.lib().gs_frame_get_info(self._h, C.byref(info)), "gs_frame_get_info")
+        self.n_points, self.n_points_in_camera, self.n_keys = info.n_points, info.n_points_in_camera, info.n_keys
+        self.n_tiles, self.sort_key_bits = info.n_tiles, info.sort_key_bits
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError("frame already released")
+        return self._h
+
+    def export(self, name: str) -> torch.Tensor:
+        eid, dtype, tail = _native.EXPORTS[name]
+        L = _native.lib()
+        n = L.gs_frame_export_count(self.handle, eid)
+        if n < 0:
+            raise RuntimeError(f"gs_frame_export_count({name}) failed")
+        rows = n
+        for d in tail:
+            rows //= d
+        out = torch.empty((rows, *tail), dtype=_TORCH_DTYPES[dtype], device=self.device)
+        if n > 0:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _native.check(L.gs_frame_export(self.handle, eid, _ptr(out), C.c_void_p(stream)), f"gs_frame_export({name})")
+        return out
+
+    def release(self):
+        if self._h is not None:
+            _native.lib().gs_frame_release(self._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class GaussianPointCloudRasterisation(torch.nn.Module):
+    @dataclass
+    class GaussianPointCloudRasterisationConfig(_ConfigBase):
+        near_plane: float = 0.8
+        far_plane: float = 1000.
+        depth_to_sort_key_scale: float = 100.
+        rgb_only: bool = False
+        # un-annotated on purpose, as in the reference (RAST:782-786): class attributes, not fields
+        grad_color_factor = 5.
+        grad_high_order_color_factor = 1.
+        grad_s_factor = 0.5
+        grad_q_factor = 1.
+        grad_alpha_factor = 20.
+
+    @dataclass
+    class GaussianPointCloudRasterisationInput:
+        point_cloud: torch.Tensor  # Nx3
+        point_cloud_features: torch.Tensor  # Nx56
+        point_object_id: torch.Tensor  # N, int32, index into the pose rows
+        point_invalid_mask: torch.Tensor  # N, int8
+        camera_info: CameraInfo
+        q_pointcloud_camera: torch.Tensor  # Kx4, xyzw
+        t_pointcloud_camera: torch.Tensor  # Kx3
+        color_max_sh_band: int = 2
+
+    @dataclass
+    class BackwardValidPointHookInput:
+        point_id_in_camera_list: torch.Tensor  # M
+        grad_point_in_camera: torch.Tensor  # Mx3
+        grad_pointfeatures_in_camera: torch.Tensor  # Mx56
+        grad_viewspace: torch.Tensor  # Mx2
+        magnitude_grad_viewspace: torch.Tensor  # M
+        magnitude_grad_viewspace_on_image: torch.Tensor  # HxWx2
+        num_overlap_tiles: torch.Tensor  # M
+        num_affected_pixels: torch.Tensor  # M
+        point_depth: torch.Tensor  # M
+        point_uv_in_camera: torch.Tensor  # Mx2
+
+    def __init__(self, config: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationConfig",
+                 backward_valid_point_hook: Optional[Callable[["GaussianPointCloudRasterisation.BackwardValidPointHookInput"], None]] = None):
+        super().__init__()
+        _native.lib()                       # fail now, loudly, if libgsrast.so is absent
+        self.config = config
+        self._hook = backward_valid_point_hook
+        self._ctxs = {}                     # device index -> gs_ctx*
+        self.last_frame: Optional[_Frame] = None   # inspection aid (tests / profiling); replaced every call
+        module = self
+
+        class _module_function(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                        q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
+                needs_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])   # False under torch.no_grad()
+                outs, frame = module._run_forward(pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                                                  q_pointcloud_camera, t_pointcloud_camera, camera_info, keep=needs_grad)
+                image, depth, acc_alpha, last, count = outs
+                ctx.frame = frame if needs_grad else None
+                ctx.camera_info = camera_info
+                ctx.color_max_sh_band = color_max_sh_band
+                ctx.save_for_backward(pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                                      q_pointcloud_camera, t_pointcloud_camera, acc_alpha, last)
+                ctx.mark_non_differentiable(count)
+                return image, depth, count
+
+            @staticmethod
+            def backward(ctx, grad_rasterized_image, grad_rasterized_depth, grad_pixel_valid_point_count):
+                grad_pointcloud = grad_pointcloud_features = None
+                if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:      # RAST:1028
+                    if ctx.frame is None:
+                        raise RuntimeError("backward through a forward that ran without gradient tracking")
+                    (pointcloud, pointcloud_features, point_invalid_mask, point_object_id, q_pointcloud_camera,
+                     t_pointcloud_camera, acc_alpha, last) = ctx.saved_tensors
+                    grad_pointcloud, grad_pointcloud_features = module._run_backward(
+                        ctx.frame, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                        q_pointcloud_camera, t_pointcloud_camera, ctx.camera_info, acc_alpha, last,
+                        grad_rasterized_image.contiguous(), ctx.color_max_sh_band)
+                    ctx.frame.release()
+                    ctx.frame = None
+                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
+
+        self._module_function = _module_function
+
+    # ------------------------------------------------------------------ helpers
+    def _ctx_for(self, device: torch.device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._ctxs:
+            h = C.c_void_p()
+            _native.check(_native.lib().gs_create(idx, C.byref(h)), "gs_create")
+            self._ctxs[idx] = h
+        return self._ctxs[idx]
+
+    def _c_config(self):
+        c = self.config
+        return _native.GsConfig(c.near_plane, c.far_plane, c.depth_to_sort_key_scale, 1 if c.rgb_only else 0,
+                                c.grad_color_factor, c.grad_high_order_color_factor, c.grad_s_factor,
+                                c.grad_q_factor, c.grad_alpha_factor)
+
+    @staticmethod
+    def _c_scene(pointcloud, features, mask, obj):
+        return _native.GsScene(_ptr(pointcloud), _ptr(features), _ptr(mask), _ptr(obj), pointcloud.shape[0])
+
+    @staticmethod
+    def _c_camera(q, t, camera_info, Kmat):
+        return _native.GsCamera(_ptr(q), _ptr(t), q.shape[0], _ptr(Kmat), camera_info.camera_height, camera_info.camera_width)
+
+    def _validate(self, pointcloud, features, mask, obj, q, t, camera_info):
+        dev = pointcloud.device
+        _require(pointcloud, "point_cloud", torch.float32, (3,))
+        _require(features, "point_cloud_features", torch.float32, (56,), dev)
+        if features.shape[0] != pointcloud.shape[0] or mask.shape[0] != pointcloud.shape[0] or obj.shape[0] != pointcloud.shape[0]:
+            raise ValueError("point_cloud, point_cloud_features, point_invalid_mask and point_object_id disagree on N")
+        _require(mask, "point_invalid_mask", torch.int8, (), dev)
+        _require(obj, "point_object_id", torch.int32, (), dev)
+        _require(q, "q_pointcloud_camera", torch.float32, (4,), dev)
+        _require(t, "t_pointcloud_camera", torch.float32, (3,), dev)
+        if q.shape[0] != t.shape[0] or q.shape[0] < 1:
+            raise ValueError("q_pointcloud_camera and t_pointcloud_camera must have the same, non-zero number of rows")
+        Kmat = camera_info.camera_intrinsics
+        if tuple(Kmat.shape) != (3, 3):
+            raise ValueError("camera_intrinsics must be 3x3")
+        if Kmat.dtype != torch.float32 or Kmat.device != dev or not Kmat.is_contiguous():
+            Kmat = Kmat.to(device=dev, dtype=torch.float32).contiguous()
+        return Kmat
+
+    def _run_forward(self, pointcloud, features, mask, obj, q, t, camera_info, keep):
+        Kmat = self._validate(pointcloud, features, mask, obj, q, t, camera_info)
+        dev = pointcloud.device
+        H, W = camera_info.camera_height, camera_info.camera_width
+        rgb_only = bool(self.config.rgb_only)
+        image = torch.empty(H, W, 3, dtype=torch.float32, device=dev)                   # RAST:967-976
+        depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+        acc_alpha = torch.empty(H, W, dtype=torch.float32, device=dev)
+        last = torch.empty(H, W, dtype=torch.int32, device=dev)
+        count = torch.empty(H, W, dtype=torch.int32, device=dev)
+        out = _native.GsForwardOut(_ptr(image), _ptr(depth), _ptr(acc_alpha), _ptr(last), _ptr(count))
+        ctxh = self._ctx_for(dev)
+        frame_h = C.c_void_p()
+        scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs_forward(ctxh, C.byref(scene), C.byref(cam), C.byref(cfg), C.byref(out),
+                                                   1 if keep else 0, C.byref(frame_h), C.c_void_p(stream)), "gs_forward")
+        frame = _Frame(ctxh, frame_h, dev)
+        if not keep:
+            frame.release = lambda: None     # transient frames belong to the ctx; nothing to release
+        self.last_frame = frame
+        return (image, depth, acc_alpha, last, count), frame
+
+    def _run_backward(self, frame, pointcloud, features, mask, obj, q, t, camera_info, acc_alpha, last, grad_image, sh_band):
+        dev = pointcloud.device
+        N, M = pointcloud.shape[0], frame.n_points_in_camera
+        H, W = camera_info.camera_height, camera_info.camera_width
+        Kmat = self._validate(pointcloud, features, mask, obj, q, t, camera_info)
+        if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (H, W, 3):
+            raise ValueError("grad of rasterized_image must be float32 (H,W,3)")
+        # one allocation for both gradients so that data-parallel training all-reduces ONE buffer
+        flat = torch.empty(N * 59, dtype=torch.float32, device=dev)
+        grad_pc = flat[:N * 3].view(N, 3)
+        grad_feat = flat[N * 3:].view(N, 56)
+        want_hook = self._hook is not None
+        e = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)
+        grad_uv = e(N, 2) if want_hook else None
+        mag = e(N) if want_hook else None
+        mag_img = e(H, W, 2) if want_hook else None
+        n_aff = e(M, dtype=torch.int32) if want_hook else None
+        h_pc = e(M, 3) if want_hook else None
+        h_feat = e(M, 56) if want_hook else None
+        h_uv = e(M, 2) if want_hook else None
+        h_mag = e(M) if want_hook else None
+        out = _native.GsBackwardOut(_ptr(grad_pc), _ptr(grad_feat), _ptr(grad_uv), _ptr(mag), _ptr(mag_img), _ptr(n_aff),
+                                    _ptr(h_pc), _ptr(h_feat), _ptr(h_uv), _ptr(h_mag))
+        scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs_backward(self._ctx_for(dev), frame.handle, C.byref(scene), C.byref(cam), C.byref(cfg),
+                                                    _ptr(grad_image), _ptr(acc_alpha), _ptr(last), int(sh_band),
+                                                    C.byref(out), C.c_void_p(stream)), "gs_backward")
+        self.last_backward_extras = dict(grad_viewspace=grad_uv, magnitude_grad_viewspace=mag,
+                                         magnitude_grad_viewspace_on_image=mag_img, num_affected_pixels=n_aff)
+        if want_hook:                                                                   # RAST:1127-1142
+            self._hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
+                point_id_in_camera_list=frame.export("point_id_in_camera_list"),
+                grad_point_in_camera=h_pc, grad_pointfeatures_in_camera=h_feat, grad_viewspace=h_uv,
+                magnitude_grad_viewspace=h_mag, magnitude_grad_viewspace_on_image=mag_img,
+                num_overlap_tiles=frame.export("num_overlap_tiles"), num_affected_pixels=n_aff,
+                point_depth=frame.export("point_depth"), point_uv_in_camera=frame.export("point_uv")))
+        return grad_pc, grad_feat
+
+    # ------------------------------------------------------------------ nn.Module
+    def forward(self, input_data: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput"):
+        camera_info = input_data.camera_info
+        assert camera_info.camera_width % TILE_WIDTH == 0        # RAST:1193-1194
+        assert camera_info.camera_height % TILE_HEIGHT == 0
+        return self._module_function.apply(
+            input_data.point_cloud, input_data.point_cloud_features, input_data.point_invalid_mask,
+            input_data.point_object_id, input_data.q_pointcloud_camera, input_data.t_pointcloud_camera,
+            camera_info, input_data.color_max_sh_band)
+
+    def __del__(self):
+        try:
+            for h in self._ctxs.values():
+                _native.lib().gs_destroy(h)
+        except Exception:
+            pass

@@ -1,0 +1,376 @@
+// gs_api.hip -- the C ABI of libgsrast.so (include/gs_rasterizer.h): context, device
+// arena, frame pool and the forward / backward orchestration that replaces
+// _module_function.forward / .backward of the reference (RAST:830-1163).
+#include "../../include/gs_rasterizer.h"
+#include "gs_common.h"
+
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(e__ == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                       \
+    } while (0)
+
+// Grow-only device buffer.  Growth (hipFree + hipMalloc) happens only when a frame is larger
+// than anything seen before; steady-state frames allocate nothing.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, int64_t* total)
+    {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = bytes + bytes / 4 + 256;     // 25 % slack: K drifts from frame to frame
+        if (p) { (void)hipFree(p); *total -= (int64_t)cap; p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want; *total += (int64_t)want;
+        return hipSuccess;
+    }
+    void release(int64_t* total) { if (p) { (void)hipFree(p); *total -= (int64_t)cap; } p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// What RAST:998-1019 saves for backward, in this library's layouts (DESIGN.md "HBM layout").
+struct FrameBufs {
+    DevBuf mask, ids, cam_index, PA, PB, PC, PD, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, tile_end, pose;
+    bool in_use = false;
+    void release(int64_t* total)
+    {
+        DevBuf* all[] = { &mask, &ids, &cam_index, &PA, &PB, &PC, &PD, &box, &ntiles, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
+                          &tile_start, &tile_end, &pose };
+        for (DevBuf* b : all) b->release(total);
+    }
+};
+
+struct gs_frame {
+    gs_ctx* ctx = nullptr;
+    FrameBufs* bufs = nullptr;
+    gs_frame_info info{};
+    int depth_bits = 0;
+    uint32_t* keys_sorted = nullptr;
+    int32_t* vals_sorted = nullptr;
+    bool live = false;
+};
+
+struct gs_ctx {
+    int device = 0;
+    std::mutex mu;
+    int64_t device_bytes = 0;
+    std::vector<FrameBufs*> pool;
+    std::vector<gs_frame*> frames;      // every handle ever issued (recycled)
+    gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
+    // scratch shared by all frames (stream ordered)
+    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial;
+    GsCounters* host_counters = nullptr;   // pinned
+};
+
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* gs_kernel_names(void)
+{
+    return "k_pose_prepare,k_filter,k_scan_blocks,k_store_M,k_compact,k_project,k_keygen,k_sort_hist,k_scan_reduce,"
+           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd,k_bwd_points";
+}
+
+extern "C" int gs_create(int32_t device, gs_ctx** out)
+{
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: out is NULL");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    gs_ctx* c = new gs_ctx();
+    c->device = device;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_counters), sizeof(GsCounters), hipHostMallocDefault);
+    if (e != hipSuccess) { delete c; return fail(GS_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    e = c->counters.ensure(sizeof(GsCounters), &c->device_bytes);
+    if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: counters"); }
+    *out = c;
+    return GS_OK;
+}
+
+extern "C" int gs_destroy(gs_ctx* c)
+{
+    if (!c) return GS_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
+    for (gs_frame* f : c->frames) delete f;
+    DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
+                      &c->counters, &c->partial };
+    for (DevBuf* b : all) b->release(&c->device_bytes);
+    if (c->host_counters) (void)hipHostFree(c->host_counters);
+    delete c;
+    return GS_OK;
+}
+
+extern "C" int64_t gs_ctx_device_bytes(const gs_ctx* c) { return c ? c->device_bytes : 0; }
+
+static FrameBufs* acquire_bufs(gs_ctx* c)
+{
+    for (FrameBufs* b : c->pool) if (!b->in_use) { b->in_use = true; return b; }
+    FrameBufs* b = new FrameBufs();
+    b->in_use = true;
+    c->pool.push_back(b);
+    return b;
+}
+
+static gs_frame* acquire_frame(gs_ctx* c)
+{
+    for (gs_frame* f : c->frames) if (!f->live) { f->live = true; return f; }
+    gs_frame* f = new gs_frame();
+    f->ctx = c; f->live = true;
+    c->frames.push_back(f);
+    return f;
+}
+
+static void drop_frame(gs_ctx* c, gs_frame* f)
+{
+    if (!f || !f->live) return;
+    if (f->bufs) f->bufs->in_use = false;
+    f->bufs = nullptr; f->live = false;
+    if (c->transient == f) c->transient = nullptr;
+}
+
+static int bits_for(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b < 1 ? 1 : b; }
+
+#define ENSURE(buf, bytes)                                                                 \
+    do {                                                                                   \
+        hipError_t e__ = (buf).ensure((bytes), &c->device_bytes);                          \
+        if (e__ != hipSuccess) { drop_frame(c, f); return fail(GS_ERR_OUT_OF_MEMORY, std::string("device allocation failed: " #buf)); } \
+    } while (0)
+
+#define HIP_TRY_F(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            drop_frame(c, f);                                                                      \
+            return fail(GS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+        }                                                                                          \
+    } while (0)
+
+extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                          const gs_forward_out* out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !out || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL argument");
+    const int H = cam->camera_height, W = cam->camera_width;
+    if (W <= 0 || H <= 0 || W % GS_TILE != 0 || H % GS_TILE != 0)        // RAST:1193-1194
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: camera_width and camera_height must be positive multiples of 16");
+    if (W / GS_TILE > 65535 || H / GS_TILE > 65535) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: image too large");
+    const int64_t N = sc->n_points;
+    if (N < 0 || N >= (int64_t)1 << 31) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_points out of range");
+    if (cam->n_objects <= 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_objects must be >= 1");
+    if (N > 0 && (!sc->point_cloud || !sc->point_cloud_features || !sc->point_invalid_mask || !sc->point_object_id))
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL scene array");
+    if (!cam->q_pointcloud_camera || !cam->t_pointcloud_camera || !cam->camera_intrinsics)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL camera array");
+    if (((uintptr_t)sc->point_cloud_features & 15u) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: point_cloud_features must be 16-byte aligned");
+    if (!out->rasterized_image) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: rasterized_image is NULL");
+    if (!cfg->rgb_only && (!out->rasterized_depth || !out->pixel_accumulated_alpha ||
+                           !out->pixel_offset_of_last_effective_point || !out->pixel_valid_point_count))
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: an output is NULL although rgb_only is false");
+    if (keep && cfg->rgb_only) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: rgb_only frames cannot be kept for backward (RAST:478-484)");
+
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->transient) drop_frame(c, c->transient);
+    gs_frame* f = acquire_frame(c);
+    f->bufs = acquire_bufs(c);
+    FrameBufs& B = *f->bufs;
+    const int T = (W / GS_TILE) * (H / GS_TILE);
+    const size_t nb = (size_t)((N + 255) / 256);
+    const size_t Np = (size_t)(N > 0 ? N : 1);
+
+    ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
+    ENSURE(B.PA, 16 * Np); ENSURE(B.PB, 16 * Np); ENSURE(B.PC, 16 * Np); ENSURE(B.PD, 16 * Np);
+    ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.offsets, 4 * Np);
+    ENSURE(B.tile_start, 4 * (size_t)T); ENSURE(B.tile_end, 4 * (size_t)T);
+    ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
+    ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
+    ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
+
+    GsProjectArgs pa{};
+    pa.point_cloud = sc->point_cloud; pa.features = sc->point_cloud_features; pa.invalid = sc->point_invalid_mask;
+    pa.object_id = sc->point_object_id; pa.N = N; pa.q_pc = cam->q_pointcloud_camera; pa.t_pc = cam->t_pointcloud_camera;
+    pa.n_objects = cam->n_objects; pa.Kmat = cam->camera_intrinsics; pa.H = H; pa.W = W;
+    pa.near_plane = cfg->near_plane; pa.far_plane = cfg->far_plane; pa.depth_scale = cfg->depth_to_sort_key_scale;
+    pa.pose = B.pose.as<GsPose>(); pa.mask = B.mask.as<int8_t>();
+    pa.block_counts = c->block_counts.as<int32_t>(); pa.block_offsets = c->block_offsets.as<int32_t>();
+    pa.ids = B.ids.as<int32_t>(); pa.cam_index = B.cam_index.as<int32_t>();
+    pa.PA = B.PA.as<float4>(); pa.PB = B.PB.as<float4>(); pa.PC = B.PC.as<float4>(); pa.PD = B.PD.as<float4>();
+    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
+    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
+    pa.counters = c->counters.as<GsCounters>();
+    gs_launch_project(pa, s);
+    HIP_TRY_F(hipGetLastError());
+    // the one device->host sync of the frame: M, K and the depth-code range
+    HIP_TRY_F(hipMemcpyAsync(c->host_counters, c->counters.p, sizeof(GsCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY_F(hipStreamSynchronize(s));
+    const int M = N > 0 ? c->host_counters->M : 0;
+    const uint32_t K = N > 0 ? c->host_counters->K : 0u;
+    const int max_code = N > 0 ? c->host_counters->max_depth_code : 0;
+    if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
+    const int depth_bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
+    const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
+    if (depth_bits + tile_bits > 32) {
+        drop_frame(c, f);
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: depth code needs " + std::to_string(depth_bits) + " bits and tile id " +
+                    std::to_string(tile_bits) + "; compact 32-bit sort keys exhausted (lower depth_to_sort_key_scale)");
+    }
+    const size_t Kp = K > 0 ? K : 1;
+    ENSURE(B.keys_a, 4 * Kp); ENSURE(B.keys_b, 4 * Kp); ENSURE(B.vals_a, 4 * Kp); ENSURE(B.vals_b, 4 * Kp);
+    const size_t hist_elems = gs_sort_hist_elems(K);
+    ENSURE(c->hist, 4 * hist_elems); ENSURE(c->scan_tmp, 4 * gs_scan_tmp_elems(hist_elems));
+
+    GsBinArgs ba{};
+    ba.N = N; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.depth_scale = cfg->depth_to_sort_key_scale;
+    ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
+    ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
+    ba.offsets = B.offsets.as<uint32_t>();
+    ba.keys_a = B.keys_a.as<uint32_t>(); ba.keys_b = B.keys_b.as<uint32_t>();
+    ba.vals_a = B.vals_a.as<int32_t>(); ba.vals_b = B.vals_b.as<int32_t>();
+    ba.hist = c->hist.as<uint32_t>(); ba.scan_tmp = c->scan_tmp.as<uint32_t>();
+    ba.tile_start = B.tile_start.as<int32_t>(); ba.tile_end = B.tile_end.as<int32_t>(); ba.T = T;
+    ba.keys_sorted = &f->keys_sorted; ba.vals_sorted = &f->vals_sorted;
+    gs_launch_binning(ba, s);
+    HIP_TRY_F(hipGetLastError());
+
+    GsBlendFwdArgs fa{};
+    fa.H = H; fa.W = W; fa.T = T; fa.rgb_only = cfg->rgb_only;
+    fa.tile_start = ba.tile_start; fa.tile_end = ba.tile_end; fa.vals_sorted = f->vals_sorted;
+    fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
+    fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
+    fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;
+    // tile ranges are all zero when K == 0, so the kernel writes the "no contributor" values itself
+    gs_launch_blend_fwd(fa, s);
+    HIP_TRY_F(hipGetLastError());
+
+    f->depth_bits = depth_bits;
+    f->info.n_points = N; f->info.n_points_in_camera = M; f->info.n_keys = K; f->info.n_tiles = T;
+    f->info.camera_height = H; f->info.camera_width = W; f->info.sort_key_bits = depth_bits + tile_bits;
+    f->info.kept_for_backward = keep ? 1 : 0;
+    if (!keep) c->transient = f;
+    *frame_out = f;
+    return GS_OK;
+}
+
+extern "C" int gs_frame_get_info(const gs_frame* f, gs_frame_info* info)
+{
+    if (!f || !info || !f->live) return fail(GS_ERR_STATE, "gs_frame_get_info: frame is not live");
+    *info = f->info;
+    return GS_OK;
+}
+
+extern "C" int64_t gs_frame_export_count(const gs_frame* f, gs_export what)
+{
+    if (!f || !f->live) return -1;
+    const int64_t M = f->info.n_points_in_camera, K = f->info.n_keys, T = f->info.n_tiles, N = f->info.n_points;
+    switch (what) {
+    case GS_X_POINT_ID_IN_CAMERA_LIST: case GS_X_POINT_ALPHA_AFTER_ACTIVATION: case GS_X_POINT_RADII:
+    case GS_X_NUM_OVERLAP_TILES: case GS_X_ACCUMULATED_NUM_OVERLAP_TILES: case GS_X_POINT_DEPTH: return M;
+    case GS_X_POINT_UV: return 2 * M;
+    case GS_X_POINT_IN_CAMERA: case GS_X_POINT_COLOR: return 3 * M;
+    case GS_X_POINT_UV_CONIC_AND_RESCALE: return 4 * M;
+    case GS_X_SORT_KEY: case GS_X_POINT_OFFSET_WITH_SORT_KEY: return K;
+    case GS_X_TILE_POINTS_START: case GS_X_TILE_POINTS_END: return T;
+    case GS_X_POINT_IN_CAMERA_MASK: return N;
+    default: return -1;
+    }
+}
+
+extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_stream stream_)
+{
+    if (!f || !f->live || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_export: frame is not live");
+    if (!dst) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: dst is NULL");
+    if (what < 0 || what >= GS_X_COUNT_) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: unknown export id");
+    gs_ctx* c = f->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const FrameBufs& B = *f->bufs;
+    GsExportArgs a{};
+    a.what = (int)what; a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = (uint32_t)f->info.n_keys;
+    a.T = f->info.n_tiles; a.depth_bits = f->depth_bits;
+    a.ids = B.ids.as<int32_t>(); a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
+    a.ntiles = B.ntiles.as<int32_t>(); a.offsets = B.offsets.as<uint32_t>();
+    a.keys_sorted = f->keys_sorted; a.vals_sorted = f->vals_sorted;
+    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_end.as<int32_t>(); a.mask = B.mask.as<int8_t>();
+    a.dst = dst;
+    gs_launch_export(a, reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                           const float* grad_image, const float* acc_alpha, const int32_t* last,
+                           int32_t sh_band, const gs_backward_out* out, gs_stream stream_)
+{
+    if (!c || !f || !sc || !cam || !cfg || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL argument");
+    if (!f->live || !f->bufs || f->ctx != c) return fail(GS_ERR_STATE, "gs_backward: frame is not live on this context");
+    if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward: frame was not kept for backward");
+    if (!grad_image || !acc_alpha || !last) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL image-sized input");
+    if (!out->grad_pointcloud || !out->grad_pointcloud_features)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: grad_pointcloud / grad_pointcloud_features are mandatory");
+    if (sc->n_points != f->info.n_points || cam->camera_height != f->info.camera_height || cam->camera_width != f->info.camera_width)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: scene/camera do not match the frame");
+    if (((uintptr_t)out->grad_pointcloud_features & 15u) != 0 || ((uintptr_t)sc->point_cloud_features & 15u) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: feature arrays must be 16-byte aligned");
+    if (out->hook_grad_pointfeatures_in_camera && ((uintptr_t)out->hook_grad_pointfeatures_in_camera & 15u) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: hook feature array must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t K = (uint32_t)f->info.n_keys;
+    {
+        hipError_t e = c->partial.ensure((size_t)(K > 0 ? K : 1) * 12 * sizeof(float), &c->device_bytes);
+        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: partial-sum buffer");
+    }
+    const FrameBufs& B = *f->bufs;
+    GsBackwardArgs a{};
+    a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = K;
+    a.H = f->info.camera_height; a.W = f->info.camera_width; a.T = f->info.n_tiles;
+    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_end.as<int32_t>(); a.vals_sorted = f->vals_sorted;
+    a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
+    a.box = B.box.as<ushort4>(); a.offsets = B.offsets.as<uint32_t>(); a.ntiles = B.ntiles.as<int32_t>();
+    a.ids = B.ids.as<int32_t>(); a.cam_index = B.cam_index.as<int32_t>();
+    a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;
+    a.partial = c->partial.as<float>();
+    a.point_cloud = sc->point_cloud; a.features = sc->point_cloud_features; a.object_id = sc->point_object_id;
+    a.Kmat = cam->camera_intrinsics; a.pose = B.pose.as<GsPose>();
+    a.sh_band = sh_band; a.f_color = cfg->grad_color_factor; a.f_high = cfg->grad_high_order_color_factor;
+    a.f_s = cfg->grad_s_factor; a.f_q = cfg->grad_q_factor; a.f_alpha = cfg->grad_alpha_factor;
+    a.grad_pc = out->grad_pointcloud; a.grad_feat = out->grad_pointcloud_features; a.grad_uv = out->grad_viewspace;
+    a.mag = out->magnitude_grad_viewspace; a.mag_image = out->magnitude_grad_viewspace_on_image;
+    a.n_affected = out->num_affected_pixels;
+    a.hook_gpc = out->hook_grad_point_in_camera; a.hook_gfeat = out->hook_grad_pointfeatures_in_camera;
+    a.hook_guv = out->hook_grad_viewspace; a.hook_mag = out->hook_magnitude_grad_viewspace;
+    gs_launch_backward(a, s);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_frame_release(gs_ctx* c, gs_frame* f)
+{
+    if (!c || !f) return GS_OK;
+    if (f->ctx != c) return fail(GS_ERR_STATE, "gs_frame_release: frame belongs to another context");
+    std::lock_guard<std::mutex> lock(c->mu);
+    drop_frame(c, f);
+    return GS_OK;
+}

@@ -1,0 +1,176 @@
+// gs_common.h -- shared declarations of libgsrast (HIP, gfx950 only).
+//
+// Arithmetic contract: every expression that decides an INDEX (frustum test, tile
+// box, depth code, the 1/255 and 1e-4 blend thresholds) is evaluated with the same
+// IEEE f32 operation sequence on every build of this library: the sources are
+// compiled with -ffp-contract=off, division and sqrt are correctly rounded (hipcc
+// default), and exp is gs_expf below (add/mul/fma only).  See DESIGN.md "Numerics".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GS_TILE_SZ 16
+#define GS_BOUNDARY_TILES 3          // reference RAST:26
+#define GS_ALPHA_EPS 0.00392156862745098f   // 1./255. (RAST:451, RAST:634)
+#define GS_ALPHA_MAX 0.99f           // RAST:453
+#define GS_T_STOP 0.0001f            // RAST:458
+#define GS_NFEAT 56
+
+// Per-object pose record built once per frame by k_pose_prepare.
+struct GsPose {
+    float R[9];          // rotation_matrix_from_quaternion(conj(q_pointcloud_camera)), GP3D:30-48
+    float t[3];          // t_camera_pointcloud, UTIL:426-432
+    float origin_fwd[3]; // camera centre as forward computes it: taichi_inverse_SE3, RAST:280-282
+    float origin_bwd[3]; // camera centre as backward reads it: t_pointcloud_camera, RAST:731-732
+    float q_cp[4];
+    float pad[2];
+};
+
+// Device-side frame counters, mirrored to pinned host memory once per forward.
+struct GsCounters {
+    int32_t M;               // points in camera
+    uint32_t K;              // sort pairs
+    int32_t max_depth_code;  // max over visible points of i32(depth * scale)
+    int32_t reserved;
+};
+
+// ---- device math -------------------------------------------------------------
+__device__ __forceinline__ float gs_expf(float x)
+{
+    if (x < -86.0f) x = -86.0f;
+    if (x > 88.0f) x = 88.0f;
+    float fx = x * 1.44269504088896341f;
+    float n = (fx + 12582912.0f) - 12582912.0f;      // round to nearest even
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float y = __builtin_fmaf(p, z, r);
+    y = y + 1.0f;
+    int32_t bits = __float_as_int(y) + (((int32_t)n) << 23);
+    return __int_as_float(bits);
+}
+
+__device__ __forceinline__ float gs_sigmoid(float x) { return 1.0f / (1.0f + gs_expf(-x)); }
+
+// C[r x c] = A[r x k] @ B[k x c]; terms summed k = 0,1,2,... like the Python matmul chain.
+template <int R, int K, int C>
+__device__ __forceinline__ void gs_mm(const float* A, const float* B, float* Cout)
+{
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float acc = A[i * K] * B[j];
+#pragma unroll
+            for (int t = 1; t < K; ++t) acc = acc + A[i * K + t] * B[t * C + j];
+            Cout[i * C + j] = acc;
+        }
+}
+
+// Tile box of a splat, RAST:81-103.  box = {min_tile_u, max_tile_u, min_tile_v, max_tile_v}
+__device__ __forceinline__ void gs_tile_box(float u, float v, float radii, int tiles_u, int tiles_v, int box[4])
+{
+    radii = radii > 1.0f ? radii : 1.0f;
+    float min_u = u - radii; min_u = min_u > 0.0f ? min_u : 0.0f;
+    float max_u = u + radii;
+    float min_v = v - radii; min_v = min_v > 0.0f ? min_v : 0.0f;
+    float max_v = v + radii;
+    int a = (int)floorf(min_u / 16.0f); a = a < tiles_u ? a : tiles_u;
+    int b = (int)floorf(max_u / 16.0f) + 1; b = b > a + 1 ? b : a + 1; b = b < tiles_u ? b : tiles_u;
+    int c = (int)floorf(min_v / 16.0f); c = c < tiles_v ? c : tiles_v;
+    int d = (int)floorf(max_v / 16.0f) + 1; d = d > c + 1 ? d : c + 1; d = d < tiles_v ? d : tiles_v;
+    box[0] = a; box[1] = b; box[2] = c; box[3] = d;
+}
+
+// wave64 helpers -----------------------------------------------------------------
+__device__ __forceinline__ int gs_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float gs_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (all of row 3).
+__device__ __forceinline__ float gs_wave_sum_row3(float v)
+{
+    v += gs_dpp<0xB1>(v);              // quad_perm [1,0,3,2]
+    v += gs_dpp<0x4E>(v);              // quad_perm [2,3,0,1]
+    v += gs_dpp<0x141>(v);             // row_half_mirror
+    v += gs_dpp<0x140>(v);             // row_mirror
+    v += gs_dpp<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
+    v += gs_dpp<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int gs_wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int gs_wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+
+// ---- host-side launch wrappers (implemented in the k_*.hip files) --------------
+struct GsProjectArgs {
+    const float* point_cloud; float* features; const int8_t* invalid; const int32_t* object_id;
+    int64_t N; const float* q_pc; const float* t_pc; int n_objects; const float* Kmat;
+    int H, W; float near_plane, far_plane, depth_scale;
+    GsPose* pose; int8_t* mask; int32_t* block_counts; int32_t* block_offsets; int32_t* ids; int32_t* cam_index;
+    float4 *PA, *PB, *PC, *PD; ushort4* box; int32_t* ntiles; uint32_t* tile_block_sums; uint32_t* tile_block_offsets;
+    GsCounters* counters;
+};
+void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
+
+struct GsBinArgs {
+    int64_t N; int M; uint32_t K; int H, W; float depth_scale; int depth_bits; int key_bits;
+    const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
+    uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
+    uint32_t *keys_a, *keys_b; int32_t *vals_a, *vals_b;   // ping-pong (K)
+    uint32_t* hist;                             // (256 * sort_blocks) + scratch
+    uint32_t* scan_tmp;                         // scratch for the scan
+    int32_t *tile_start, *tile_end; int T;
+    uint32_t** keys_sorted; int32_t** vals_sorted;   // out: which of a/b holds the result
+};
+void gs_launch_binning(const GsBinArgs& a, hipStream_t s);
+size_t gs_sort_hist_elems(uint32_t K);
+size_t gs_scan_tmp_elems(size_t n);
+
+struct GsBlendFwdArgs {
+    int H, W, T; int rgb_only;
+    const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
+    const float4 *PA, *PB, *PC;
+    float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
+};
+void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
+
+struct GsBackwardArgs {
+    int64_t N; int M; uint32_t K; int H, W, T;
+    const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
+    const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;
+    const int32_t* ids; const int32_t* cam_index;
+    const float* grad_image; const float* acc_alpha; const int32_t* last;
+    float* partial;                 // (K,12) per (point,tile) sums in slot order
+    const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;
+    int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
+    float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;
+    float* hook_gpc; float* hook_gfeat; float* hook_guv; float* hook_mag;
+};
+void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s);
+
+struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_bits;
+    const int32_t* ids; const float4 *PA, *PB, *PC, *PD; const int32_t* ntiles; const uint32_t* offsets;
+    const uint32_t* keys_sorted; const int32_t* vals_sorted; const int32_t *tile_start, *tile_end; const int8_t* mask; void* dst; };
+void gs_launch_export(const GsExportArgs& a, hipStream_t s);

@@ -1,0 +1,368 @@
+// k_backward.hip -- gaussian_point_rasterisation_backward, RAST:488-772, plus the torch
+// post-processing RAST:1102-1140, as two kernels and NO global atomics:
+//
+//   k_blend_bwd   loop 1 (RAST:531-705).  One workgroup per tile, each wave owns an 8x8
+//                 quadrant and walks the list back to front.  The 11 per-contribution
+//                 quantities the reference sends to HBM with ti.atomic_add (RAST:674-696) are
+//                 summed over the wave's 64 pixels with DPP, combined over the 4 waves in LDS,
+//                 and stored ONCE per (point, tile) pair as a 12-float row of `partial`, at the
+//                 pair's pre-sort slot (offsets[p] + position of the tile in p's tile box), so
+//                 all rows of a point are contiguous.
+//   k_bwd_points  loop 2 (RAST:708-772) over all N rows: sums a point's rows in slot order
+//                 (deterministic), chains the Jacobians (GP3D:132-159, 237-331, 351-373),
+//                 applies band masks and grad factors (RAST:1102-1125, 1167-1182) and writes
+//                 every output row exactly once (zero for rows outside the frustum), including
+//                 the BackwardValidPointHookInput gathers (RAST:1128-1140).
+// k_blend_bwd is VALU/LDS bound, k_bwd_points HBM bound: see DESIGN.md.
+#include "gs_common.h"
+
+#define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count | pad
+
+__device__ __forceinline__ float rect_min_quadratic_b(float a, float b, float c, float X0, float X1, float Y0, float Y1)
+{
+    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float X = e ? X1 : X0;
+        float y = -(b * X) / c;
+        y = fminf(fmaxf(y, Y0), Y1);
+        best = fminf(best, a * X * X + 2.0f * b * X * y + c * y * y);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float Y = e ? Y1 : Y0;
+        float x = -(b * Y) / a;
+        x = fminf(fmaxf(x, X0), X1);
+        best = fminf(best, a * x * x + 2.0f * b * x * Y + c * Y * Y);
+    }
+    return best;
+}
+
+__device__ __forceinline__ bool gs_cull_b(float4 A, float4 B, float4 C, float rx0, float ry0)
+{
+    float a = A.z, b = A.w, c = B.x;
+    float X0 = rx0 - A.x, X1 = X0 + 7.0f, Y0 = ry0 - A.y, Y1 = Y0 + 7.0f;
+    float ax = fmaxf(fabsf(X0), fabsf(X1)), ay = fmaxf(fabsf(Y0), fabsf(Y1));
+    float slack = 0.02f + 4.0e-6f * (fabsf(a) * ax * ax + fabsf(c) * ay * ay + 2.0f * fabsf(b) * ax * ay);
+    bool pd = a > 0.0f && c > 0.0f && a * c > b * b;
+    float qmin = rect_min_quadratic_b(a, b, c, X0, X1, Y0, Y1);
+    return pd && (-0.5f * qmin + slack < C.w);
+}
+
+__global__ __launch_bounds__(256) void k_blend_bwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                   const int32_t* __restrict__ sorted_vals,
+                                                   const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                   const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
+                                                   const uint32_t* __restrict__ offsets,
+                                                   const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
+                                                   const int32_t* __restrict__ last_in, int W, int tiles_x,
+                                                   float* __restrict__ partial, float* __restrict__ mag_image)
+{
+    __shared__ float4 sA[4][64], sB[4][64], sC[4][64];
+    __shared__ float4 acc[4][64][3];
+    __shared__ unsigned long long hit[4];
+    __shared__ int wmax[4];
+    const int tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
+    const int qx = tile_u * 16 + (wave & 1) * 8, qy = tile_v * 16 + (wave >> 1) * 8;
+    const int pixel_u = qx + (lane & 7), pixel_v = qy + (lane >> 3);
+    const float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
+    const float rx0 = (float)qx + 0.5f, ry0 = (float)qy + 0.5f;
+    const int start = tile_start[tile], end = tile_end[tile];
+    const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
+
+    const int last = last_in[o];                                   // RAST:558
+    float T_i = 1.0f - acc_alpha[o];                               // RAST:559-560
+    float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
+    const float gr = grad_image[3 * o], gg = grad_image[3 * o + 1], gb = grad_image[3 * o + 2];
+    float tot0 = 0.0f, tot1 = 0.0f;
+
+    const int wave_last = gs_wave_max_i(last);
+    if (lane == 0) wmax[wave] = wave_last;
+    __syncthreads();
+    const int tile_last = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+
+    for (int hi = end; hi > start; hi -= 64) {
+        const int lo = max(start, hi - 64);
+        unsigned long long my_hits = 0ull;
+        if (lo < tile_last && lo < wave_last) {
+            const int i = lo + lane;
+            const bool valid = i < hi && i < wave_last;
+            const int p = (i < hi) ? sorted_vals[i] : 0;
+            float4 A = PA[p], B = PB[p], C = PC[p];
+            bool keep = valid && !gs_cull_b(A, B, C, rx0, ry0);
+            unsigned long long mask = __ballot(keep);
+            if (mask) {
+                sA[wave][lane] = A; sB[wave][lane] = B; sC[wave][lane] = C;
+                __builtin_amdgcn_wave_barrier();
+                while (mask) {
+                    const int j = 63 - __builtin_clzll(mask);             // back to front, RAST:605-608
+                    mask &= ~(1ull << j);
+                    const float4 a4 = sA[wave][j], b4 = sB[wave][j], c4 = sC[wave][j];
+                    const float a = a4.z, b = a4.w, c = b4.x;
+                    // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
+                    float dx = px - a4.x, dy = py - a4.y;
+                    float cix = a * dx + b * dy, ciy = b * dx + c * dy;
+                    float quad = dx * cix + dy * ciy;
+                    float exponent = -0.5f * quad;
+                    const bool in_range = (lo + j) < last;                // RAST:609-610
+                    if (!__any(in_range && !(exponent + 0.02f < c4.w))) continue;
+                    float g = gs_expf(exponent) * b4.y;
+                    float apt = b4.z;
+                    float prod_alpha = g * apt;
+                    const bool use = in_range && prod_alpha >= GS_ALPHA_EPS;      // RAST:634
+                    if (!__any(use)) continue;
+                    float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
+                    float one_m = 1.0f - alpha;
+                    float inv = 1.0f / one_m;
+                    float Tn = T_i / one_m;                                       // RAST:643
+                    float d_rgb = alpha * Tn;
+                    float ag = (c4.x * Tn - w0 * inv) * gr + (c4.y * Tn - w1 * inv) * gg + (c4.z * Tn - w2 * inv) * gb;  // RAST:653-657
+                    float gag = ag * apt;                                         // RAST:662
+                    float hg = 0.5f * g * gag;
+                    float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);           // RAST:664-665
+                    float v[11];
+                    v[0] = use ? vs0 : 0.0f;
+                    v[1] = use ? vs1 : 0.0f;
+                    v[2] = use ? hg * cix * cix : 0.0f;                           // d p / d cov = 0.5 p (S^-1 d)(S^-1 d)^T
+                    v[3] = use ? hg * cix * ciy : 0.0f;
+                    v[4] = use ? hg * ciy * ciy : 0.0f;
+                    v[5] = use ? d_rgb * gr : 0.0f;                               // RAST:649-650
+                    v[6] = use ? d_rgb * gg : 0.0f;
+                    v[7] = use ? d_rgb * gb : 0.0f;
+                    v[8] = use ? (ag * g) * (1.0f - apt) * apt : 0.0f;            // RAST:658-661
+                    v[9] = use ? __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1) : 0.0f;   // RAST:691-694
+                    v[10] = use ? 1.0f : 0.0f;                                    // RAST:695-696
+                    if (use) {
+                        T_i = Tn;
+                        w0 += c4.x * alpha * Tn; w1 += c4.y * alpha * Tn; w2 += c4.z * alpha * Tn;   // RAST:656
+                        tot0 += fabsf(vs0); tot1 += fabsf(vs1);                   // RAST:666-667
+                    }
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) v[k] = gs_wave_sum_row3(v[k]);
+                    if (lane == 63) {
+                        acc[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
+                        acc[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
+                        acc[wave][j][2] = make_float4(v[8], v[9], v[10], 0.0f);
+                    }
+                    my_hits |= 1ull << j;
+                }
+            }
+        }
+        if (lane == 0) hit[wave] = my_hits;
+        __syncthreads();
+        {   // one 12-float row per (point, tile) pair, stored at the pair's pre-sort slot
+            const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
+            const int i = lo + e;
+            if (i < hi) {
+                const int p = sorted_vals[i];
+                const ushort4 bx = boxes[p];
+                const uint32_t slot = offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z));
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if ((hit[w] >> e) & 1ull) {
+                        const float* r = reinterpret_cast<const float*>(&acc[w][e][0]) + part * 3;
+                        s0 += r[0]; s1 += r[1]; s2 += r[2];
+                    }
+                float* dst = partial + (size_t)slot * PW + part * 3;
+                dst[0] = s0; dst[1] = s1; dst[2] = s2;
+            }
+        }
+        __syncthreads();
+    }
+    if (mag_image) { mag_image[2 * o] = tot0; mag_image[2 * o + 1] = tot1; }   // RAST:700-704
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwd_points(
+    int64_t N, const int32_t* __restrict__ cam_index, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
+    const float* __restrict__ partial, const float4* __restrict__ PD,
+    const float* __restrict__ pc, const float* __restrict__ feat, const int32_t* __restrict__ obj,
+    const float* __restrict__ Kmat, const GsPose* __restrict__ pose,
+    int keep, float f_color, float f_high, float f_s, float f_q, float f_alpha,
+    float* __restrict__ grad_pc, float* __restrict__ grad_feat, float* __restrict__ grad_uv, float* __restrict__ mag,
+    int32_t* __restrict__ n_affected,
+    float* __restrict__ hook_gpc, float* __restrict__ hook_gfeat, float* __restrict__ hook_guv, float* __restrict__ hook_mag)
+{
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m = cam_index[n];
+    float4* gf4 = reinterpret_cast<float4*>(grad_feat + (size_t)GS_NFEAT * n);
+    if (m < 0) {                                                    // RAST:1051-1058 zero rows
+        grad_pc[3 * n] = 0.0f; grad_pc[3 * n + 1] = 0.0f; grad_pc[3 * n + 2] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < GS_NFEAT / 4; ++k) gf4[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (grad_uv) { grad_uv[2 * n] = 0.0f; grad_uv[2 * n + 1] = 0.0f; }
+        if (mag) mag[n] = 0.0f;
+        return;
+    }
+    // ---- sum this point's rows (slot order) ----
+    float s[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) s[k] = 0.0f;
+    {
+        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)offsets[m] * PW);
+        const int cnt = ntiles[m];
+        for (int i = 0; i < cnt; ++i) {
+            float4 r0 = rows[3 * i], r1 = rows[3 * i + 1], r2 = rows[3 * i + 2];
+            s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
+            s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
+            s[8] += r2.x; s[9] += r2.y; s[10] += r2.z;
+        }
+    }
+    const float guv0 = s[0], guv1 = s[1];
+    const float g00 = s[2], g01 = s[3], g11 = s[4];
+    const float4* row4 = reinterpret_cast<const float4*>(feat + (size_t)GS_NFEAT * n);
+    float row[GS_NFEAT];
+#pragma unroll
+    for (int k = 0; k < GS_NFEAT / 4; ++k) {
+        float4 v = row4[k];
+        row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+    }
+    const GsPose& P = pose[obj[n]];
+    float Km[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Km[k] = Kmat[k];
+    const float x = pc[3 * n], y = pc[3 * n + 1], z = pc[3 * n + 2];
+    // ---- d uv / d xyz, GP3D:132-159 ----
+    float tx = ((P.R[0] * x + P.R[1] * y) + P.R[2] * z) + P.t[0];
+    float ty = ((P.R[3] * x + P.R[4] * y) + P.R[5] * z) + P.t[1];
+    float tz = ((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2];
+    float d[6] = { Km[0] / tz, Km[1] / tz, (-Km[0] * tx - Km[1] * ty) / (tz * tz),
+                   Km[3] / tz, Km[4] / tz, (-Km[3] * tx - Km[4] * ty) / (tz * tz) };
+    float gcam[3] = { guv0 * d[0] + guv1 * d[3], guv0 * d[1] + guv1 * d[4], guv0 * d[2] + guv1 * d[5] };
+    float gt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gt[j] = gcam[0] * P.R[j] + gcam[1] * P.R[3 + j] + gcam[2] * P.R[6 + j];   // RAST:757
+    // ---- d Sigma' / d(q, s), GP3D:237-331, contracted with (g00 g01; g01 g11) ----
+    const float4 pd = PD[m];                                        // translation_camera, RAST:737-738
+    const float fx = Km[0], fy = Km[4];
+    float J[6] = { fx / pd.z, 0.0f, -(fx * pd.x) / (pd.z * pd.z), 0.0f, fy / pd.z, -(fy * pd.y) / (pd.z * pd.z) };
+    float U[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        U[j] = J[0] * P.R[j] + J[2] * P.R[6 + j];
+        U[3 + j] = J[4] * P.R[3 + j] + J[5] * P.R[6 + j];
+    }
+    const float qx = row[0], qy = row[1], qz = row[2], qw = row[3];
+    float R[9];
+    {
+        float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+        R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz); R[2] = 2.0f * (xz + wy);
+        R[3] = 2.0f * (xy + wz); R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
+        R[6] = 2.0f * (xz - wy); R[7] = 2.0f * (yz + wx); R[8] = 1.0f - 2.0f * (xx + yy);
+    }
+    const float es[3] = { gs_expf(row[4]), gs_expf(row[5]), gs_expf(row[6]) };
+    float Mm[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Mm[3 * i + j] = R[3 * i + j] * es[j];       // M = R S, GP3D:257
+    float UM[6];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) UM[3 * a + j] = U[3 * a] * Mm[j] + U[3 * a + 1] * Mm[3 + j] + U[3 * a + 2] * Mm[6 + j];
+    float gUM[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { gUM[j] = g00 * UM[j] + g01 * UM[3 + j]; gUM[3 + j] = g01 * UM[j] + g11 * UM[3 + j]; }
+    float GM[9];   // dL/dM = 2 U^T g (U M)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) GM[3 * i + j] = 2.0f * (U[i] * gUM[j] + U[3 + i] * gUM[3 + j]);
+    float gs_[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gs_[j] = (GM[j] * R[j] + GM[3 + j] * R[3 + j] + GM[6 + j] * R[6 + j]) * es[j];   // GP3D:297-313
+    const float sx = es[0], sy = es[1], sz = es[2];
+    // dM/dq, GP3D:319-329 (rows = M entries 00 01 02 10 11 12 20 21 22; columns = q x y z w)
+    const float dMdq[36] = {
+        0.0f, -4 * sx * qy, -4 * sx * qz, 0.0f,
+        2 * sy * qy, 2 * sy * qx, -2 * sy * qw, -2 * sy * qz,
+        2 * sz * qz, 2 * sz * qw, 2 * sz * qx, 2 * sz * qy,
+        2 * sx * qy, 2 * sx * qx, 2 * sx * qw, 2 * sx * qz,
+        -4 * sy * qx, 0.0f, -4 * sy * qz, 0.0f,
+        -2 * sz * qw, 2 * sz * qz, 2 * sz * qy, -2 * sz * qx,
+        2 * sx * qz, -2 * sx * qw, 2 * sx * qx, -2 * sx * qy,
+        2 * sy * qw, 2 * sy * qz, 2 * sy * qy, 2 * sy * qx,
+        -4 * sz * qx, -4 * sz * qy, 0.0f, 0.0f };
+    float gq[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gq[k] += GM[e] * dMdq[4 * e + k];
+    // ---- colour, GP3D:351-373 with the backward's ray origin (RAST:731-732, 749) ----
+    float dx = x - P.origin_bwd[0], dy = y - P.origin_bwd[1], dz = z - P.origin_bwd[2];
+    float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    float ux = dx / dn, uy = dy / dn, uz = dz / dn;
+    float sh[16];
+    sh[0] = 0.28209479177387814f;
+    sh[1] = -0.48860251190291987f * uy;
+    sh[2] = 0.48860251190291987f * uz;
+    sh[3] = -0.48860251190291987f * ux;
+    sh[4] = 1.0925484305920792f * ux * uy;
+    sh[5] = -1.0925484305920792f * uy * uz;
+    sh[6] = 0.94617469575755997f * uz * uz - 0.31539156525251999f;
+    sh[7] = -1.0925484305920792f * ux * uz;
+    sh[8] = 0.54627421529603959f * ux * ux - 0.54627421529603959f * uy * uy;
+    sh[9] = 0.59004358992664352f * uy * (-3.0f * ux * ux + uy * uy);
+    sh[10] = 2.8906114426405538f * ux * uy * uz;
+    sh[11] = 0.45704579946446572f * uy * (1.0f - 5.0f * uz * uz);
+    sh[12] = 0.3731763325901154f * uz * (5.0f * uz * uz - 3.0f);
+    sh[13] = 0.45704579946446572f * ux * (1.0f - 5.0f * uz * uz);
+    sh[14] = 1.4453057213202769f * uz * (ux * ux - uy * uy);
+    sh[15] = 0.59004358992664352f * ux * (-ux * ux + 3.0f * uy * uy);
+    float out[GS_NFEAT];
+    out[0] = gq[0] * f_q; out[1] = gq[1] * f_q; out[2] = gq[2] * f_q; out[3] = gq[3] * f_q;      // RAST:1105-1106
+    out[4] = gs_[0] * f_s; out[5] = gs_[1] * f_s; out[6] = gs_[2] * f_s;                          // RAST:1107-1108
+    out[7] = s[8] * f_alpha;                                                                      // RAST:1109-1110
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* f = row + 8 + 16 * ch;
+        float accd = f[0] * sh[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) accd = accd + f[k] * sh[k];
+        float sg = gs_sigmoid(accd);
+        float jac = sg * (1.0f - sg);
+        float gc = s[5 + ch];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = gc * (jac * sh[k]);                           // RAST:754-756
+            v = k < keep ? v * (k == 0 ? f_color : f_high) : 0.0f;  // RAST:1167-1182, 1112-1125
+            out[8 + 16 * ch + k] = v;
+        }
+    }
+    grad_pc[3 * n] = gt[0]; grad_pc[3 * n + 1] = gt[1]; grad_pc[3 * n + 2] = gt[2];
+#pragma unroll
+    for (int k = 0; k < GS_NFEAT / 4; ++k) gf4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    if (grad_uv) { grad_uv[2 * n] = guv0; grad_uv[2 * n + 1] = guv1; }
+    if (mag) mag[n] = s[9];
+    if (n_affected) n_affected[m] = (int32_t)(s[10] + 0.5f);
+    if (hook_gpc) { hook_gpc[3 * (size_t)m] = gt[0]; hook_gpc[3 * (size_t)m + 1] = gt[1]; hook_gpc[3 * (size_t)m + 2] = gt[2]; }
+    if (hook_gfeat) {
+        float4* h4 = reinterpret_cast<float4*>(hook_gfeat + (size_t)GS_NFEAT * m);
+#pragma unroll
+        for (int k = 0; k < GS_NFEAT / 4; ++k) h4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+    if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
+    if (hook_mag) hook_mag[m] = s[9];
+}
+
+void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
+{
+    if (a.T > 0 && a.K > 0)
+        k_blend_bwd<<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
+                                        a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.mag_image);
+    else if (a.mag_image)
+        (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
+    const int nb = (int)((a.N + 255) / 256);
+    if (nb == 0) return;
+    int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
+    k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.PD, a.point_cloud, a.features,
+                                    a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
+                                    a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
+                                    a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag);
+}

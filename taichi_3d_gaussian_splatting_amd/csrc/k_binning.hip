@@ -1,0 +1,195 @@
+// k_binning.hip -- tile binning: key build, stable LSD radix sort, per-tile ranges.
+//   k_keygen        generate_point_sort_key_by_num_overlap_tiles, RAST:131-172, with the
+//                   exclusive scan of RAST:913-922 folded in (block-local scan + block offset)
+//   k_sort_hist / k_sort_scatter   Tensor.sort() + gather, RAST:947-949 (stable: ties keep
+//                   ascending in-camera offset)
+//   k_tile_ranges   find_tile_start_and_end, RAST:175-193
+//
+// Keys are stored compactly: (tile_id << depth_bits) | depth_code, depth_bits = bits of the
+// largest depth code in THIS frame, so only the significant bits are radix-sorted.  The order
+// is identical to sorting the reference's 64-bit (tile_id << 32) + depth_code keys; exports
+// rebuild those.  HBM-bound integer work: no LDS reshaping beyond per-wave digit counters.
+#include "gs_common.h"
+#include "gs_scan.h"
+
+#define SORT_TILE 4096          // keys per tile: 256 threads x 16
+#define SORT_ROUNDS 16
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, const ushort4* __restrict__ boxes,
+                                                const int32_t* __restrict__ ntiles,
+                                                const uint32_t* __restrict__ tile_block_offsets, int M, int tiles_x,
+                                                float depth_scale, int depth_bits, uint32_t K_cap,
+                                                uint32_t* __restrict__ offsets, KeyT* __restrict__ keys,
+                                                int32_t* __restrict__ vals)
+{
+    __shared__ uint32_t ws[4];
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t n = idx < M ? (uint32_t)ntiles[idx] : 0u;
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += ws[w];
+    if (idx >= M) return;
+    uint32_t off = tile_block_offsets[blockIdx.x] + woff + incl - n;
+    offsets[idx] = off;
+    ushort4 bx = boxes[idx];
+    int depth_code = (int)(PB[idx].w * depth_scale);                 // RAST:159-160
+    int dv = (int)bx.w - (int)bx.z;
+    for (int tu = bx.x; tu < bx.y; ++tu)
+        for (int tv = bx.z; tv < bx.w; ++tv) {
+            uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
+            if (slot < K_cap) {
+                KeyT tile_id = (KeyT)(tu + tv * tiles_x);                       // RAST:167-168
+                keys[slot] = (tile_id << depth_bits) | (KeyT)(uint32_t)depth_code;
+                vals[slot] = idx;
+            }
+        }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys, uint32_t n, int shift,
+                                                   uint32_t* __restrict__ hist, int nblocks, int tiles_per_block)
+{
+    __shared__ uint32_t lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * SORT_TILE;
+    uint64_t end = begin + (uint64_t)tiles_per_block * SORT_TILE;
+    if (end > n) end = n;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += 256)
+        atomicAdd(&lh[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                      KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                                                      uint32_t n, int shift, const uint32_t* __restrict__ hist_scanned,
+                                                      int nblocks, int tiles_per_block)
+{
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t gbase[256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    gbase[t] = hist_scanned[t * nblocks + blockIdx.x];
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tile) * SORT_TILE;
+        if (tile_base >= n) break;
+        cnt[0][t] = 0; cnt[1][t] = 0; cnt[2][t] = 0; cnt[3][t] = 0;
+        __syncthreads();
+        KeyT k[SORT_ROUNDS];
+        int32_t v[SORT_ROUNDS];
+        uint32_t rank[SORT_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SORT_ROUNDS; ++r) {
+            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            bool valid = i < n;
+            k[r] = valid ? keys_in[i] : (KeyT)0;
+            v[r] = valid ? vals_in[i] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < SORT_ROUNDS; ++r) {
+            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            bool valid = i < n;
+            uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                bool b = (d >> bit) & 1u;
+                unsigned long long bal = __ballot(b);
+                same &= b ? bal : ~bal;
+            }
+            uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
+            uint32_t before = valid ? cnt[wave][d] : 0u;
+            if (valid && in_round == 0) cnt[wave][d] = before + (uint32_t)__popcll(same);
+            rank[r] = before + in_round;
+        }
+        __syncthreads();
+        {
+            uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+            uint32_t g = gbase[t];
+            cnt[0][t] = g; cnt[1][t] = g + c0; cnt[2][t] = g + c0 + c1; cnt[3][t] = g + c0 + c1 + c2;
+            gbase[t] = g + c0 + c1 + c2 + c3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ROUNDS; ++r) {
+            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            if (i < n) {
+                uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+                uint32_t pos = cnt[wave][d] + rank[r];
+                keys_out[pos] = k[r];
+                vals_out[pos] = v[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tile_ranges(const KeyT* __restrict__ keys, uint32_t n, int depth_bits,
+                                                     int32_t* __restrict__ tile_start, int32_t* __restrict__ tile_end)
+{
+    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n) return;
+    int32_t tile = (int32_t)(keys[idx] >> depth_bits);
+    if (idx + 1 < n) {
+        int32_t next = (int32_t)(keys[idx + 1] >> depth_bits);
+        if (tile != next) { tile_start[next] = (int32_t)(idx + 1); tile_end[tile] = (int32_t)(idx + 1); }
+    } else {
+        tile_end[tile] = (int32_t)n;
+    }
+}
+
+static void sort_geometry(uint32_t K, int* nblocks, int* tiles_per_block)
+{
+    uint32_t tiles = (K + SORT_TILE - 1) / SORT_TILE;
+    uint32_t target = tiles < 1024u ? tiles : 1024u;
+    if (target == 0) target = 1;
+    *tiles_per_block = (int)((tiles + target - 1) / target);
+    if (*tiles_per_block < 1) *tiles_per_block = 1;
+    *nblocks = (int)((tiles + *tiles_per_block - 1) / *tiles_per_block);
+    if (*nblocks < 1) *nblocks = 1;
+}
+
+size_t gs_sort_hist_elems(uint32_t K)
+{
+    int nb, tpb;
+    sort_geometry(K, &nb, &tpb);
+    return (size_t)256 * nb;
+}
+
+size_t gs_scan_tmp_elems(size_t n) { return 2 * ((n + GS_SCAN_CHUNK - 1) / GS_SCAN_CHUNK) + 16; }
+
+void gs_launch_binning(const GsBinArgs& a, hipStream_t s)
+{
+    (void)hipMemsetAsync(a.tile_start, 0, sizeof(int32_t) * a.T, s);     // RAST:954-957
+    (void)hipMemsetAsync(a.tile_end, 0, sizeof(int32_t) * a.T, s);
+    *a.keys_sorted = a.keys_a;
+    *a.vals_sorted = a.vals_a;
+    const int nbM = (int)((a.N + 255) / 256);
+    if (nbM == 0 || a.M == 0) return;
+    k_keygen<uint32_t><<<(a.M + 255) / 256, 256, 0, s>>>(a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.W / GS_TILE_SZ,
+                                                         a.depth_scale, a.depth_bits, a.K, a.offsets, a.keys_a, a.vals_a);
+    if (a.K == 0) return;
+    int nb, tpb;
+    sort_geometry(a.K, &nb, &tpb);
+    uint32_t *kin = a.keys_a, *kout = a.keys_b;
+    int32_t *vin = a.vals_a, *vout = a.vals_b;
+    for (int shift = 0; shift < a.key_bits; shift += 8) {
+        k_sort_hist<uint32_t><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb);
+        gs_scan_u32(a.hist, a.hist, 256 * nb, a.scan_tmp, nullptr, s);
+        k_sort_scatter<uint32_t><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, a.hist, nb, tpb);
+        uint32_t* tk = kin; kin = kout; kout = tk;
+        int32_t* tv = vin; vin = vout; vout = tv;
+    }
+    *a.keys_sorted = kin;
+    *a.vals_sorted = vin;
+    k_tile_ranges<uint32_t><<<(a.K + 255) / 256, 256, 0, s>>>(kin, a.K, a.depth_bits, a.tile_start, a.tile_end);
+}

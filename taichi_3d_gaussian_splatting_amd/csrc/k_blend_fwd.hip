@@ -1,0 +1,137 @@
+// k_blend_fwd.hip -- front-to-back alpha blend, gaussian_point_rasterisation RAST:318-485.
+//
+// CDNA4 mapping (not the reference's 256-thread/one-barrier-per-batch scheme):
+//   * one workgroup (256 threads = 4 waves) per 16x16 tile, but each WAVE owns an 8x8
+//     pixel quadrant and walks the tile's sorted list on its own: no __syncthreads at all,
+//     so a quadrant that saturates stops while its neighbours continue;
+//   * per 64-entry batch every lane fetches one splat record (3 x float4, gathered by the
+//     sorted index) and tests it against the wave's 8x8 rectangle with a conservative
+//     bound on the Gaussian exponent; a 64-bit ballot keeps only splats that can reach
+//     alpha >= 1/255 somewhere in the quadrant, and the wave iterates the set bits;
+//   * survivors are re-read from a wave-private LDS slab with broadcast ds_read_b128.
+// Culling is invisible in the results: a culled splat would have been skipped by the
+// alpha < 1/255 test for every pixel of the quadrant (RAST:451-452).
+// Bound: FP32 VALU (exp polynomial + blend), not HBM: see DESIGN.md.
+#include "gs_common.h"
+
+// min over the rectangle [X0,X1]x[Y0,Y1] (pixel centre minus mean) of q = a x^2 + 2 b x y + c y^2
+__device__ __forceinline__ float rect_min_quadratic(float a, float b, float c, float X0, float X1, float Y0, float Y1)
+{
+    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
+    float best = 3.0e38f;
+    // edges x = X0, X1 : minimise over y
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float X = e ? X1 : X0;
+        float y = -(b * X) / c;
+        y = fminf(fmaxf(y, Y0), Y1);
+        float q = a * X * X + 2.0f * b * X * y + c * y * y;
+        best = fminf(best, q);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float Y = e ? Y1 : Y0;
+        float x = -(b * Y) / a;
+        x = fminf(fmaxf(x, X0), X1);
+        float q = a * x * x + 2.0f * b * x * Y + c * Y * Y;
+        best = fminf(best, q);
+    }
+    return best;
+}
+
+// true when the splat cannot reach alpha >= 1/255 anywhere in the rectangle.
+// Written so that any NaN makes the test false (= keep the splat).
+__device__ __forceinline__ bool gs_cull(float4 A, float4 B, float4 C, float rx0, float ry0)
+{
+    float a = A.z, b = A.w, c = B.x;
+    float X0 = rx0 - A.x, X1 = X0 + 7.0f, Y0 = ry0 - A.y, Y1 = Y0 + 7.0f;
+    float ax = fmaxf(fabsf(X0), fabsf(X1)), ay = fmaxf(fabsf(Y0), fabsf(Y1));
+    // rounding slack of the f32 exponent evaluated per pixel (terms can cancel for skewed conics)
+    float slack = 0.02f + 4.0e-6f * (fabsf(a) * ax * ax + fabsf(c) * ay * ay + 2.0f * fabsf(b) * ax * ay);
+    bool pd = a > 0.0f && c > 0.0f && a * c > b * b;
+    float qmin = rect_min_quadratic(a, b, c, X0, X1, Y0, Y1);
+    return pd && (-0.5f * qmin + slack < C.w);
+}
+
+template <bool RGB_ONLY>
+__global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                   const int32_t* __restrict__ sorted_vals,
+                                                   const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                   const float4* __restrict__ PC, int W, int tiles_x,
+                                                   float* __restrict__ image, float* __restrict__ depth_out,
+                                                   float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
+                                                   int32_t* __restrict__ count_out)
+{
+    __shared__ float4 sA[4][64], sB[4][64], sC[4][64];
+    const int tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
+    const int qx = tile_u * 16 + (wave & 1) * 8, qy = tile_v * 16 + (wave >> 1) * 8;
+    const int pixel_u = qx + (lane & 7), pixel_v = qy + (lane >> 3);
+    const float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
+    const float rx0 = (float)qx + 0.5f, ry0 = (float)qy + 0.5f;
+    const int start = tile_start[tile], end = tile_end[tile];
+
+    float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, acc_d = 0.0f, norm = 0.0f;
+    int last = start, count = 0;
+    bool saturated = false;
+
+    for (int base = start; base < end; base += 64) {
+        if (__all(saturated)) break;
+        const int i = base + lane;
+        const bool valid = i < end;
+        const int p = valid ? sorted_vals[i] : 0;
+        float4 A = PA[p], B = PB[p], C = PC[p];
+        bool keep = valid && !gs_cull(A, B, C, rx0, ry0);
+        unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) continue;
+        sA[wave][lane] = A; sB[wave][lane] = B; sC[wave][lane] = C;
+        __builtin_amdgcn_wave_barrier();
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const float4 a4 = sA[wave][j], b4 = sB[wave][j], c4 = sC[wave][j];
+            // get_point_probability_density_from_conic_and_rescale, UTIL:275-284 (same op order)
+            float dx = px - a4.x, dy = py - a4.y;
+            float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
+            // cheap wave-level reject before the polynomial: exp(e)*rescale*opacity < 1/255 for sure
+            if (!__any(!saturated && !(exponent + 0.02f < c4.w))) continue;
+            float g = gs_expf(exponent) * b4.y;
+            float alpha = g * b4.z;
+            bool use = !saturated && !(alpha < GS_ALPHA_EPS);                    // RAST:451
+            alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                // RAST:453
+            float next_T = T_i * (1.0f - alpha);                                // RAST:457
+            bool sat_now = use && next_T < GS_T_STOP;                           // RAST:458-460
+            saturated = saturated || sat_now;
+            use = use && !sat_now;
+            if (use) {
+                last = base + j + 1;                                            // RAST:461
+                // same association as the reference (colour * alpha * T_i), so the image is bit-exact
+                cr += c4.x * alpha * T_i; cg += c4.y * alpha * T_i; cb += c4.z * alpha * T_i;   // RAST:462
+                if (!RGB_ONLY) { acc_d += b4.w * alpha * T_i; norm += alpha * T_i; count += 1; } // RAST:464-469
+                T_i = next_T;
+            }
+            if (__all(saturated)) { mask = 0ull; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
+    image[3 * o] = cr; image[3 * o + 1] = cg; image[3 * o + 2] = cb;
+    if (!RGB_ONLY) {
+        depth_out[o] = acc_d / (norm > 1e-6f ? norm : 1e-6f);                  // RAST:479-480
+        acc_alpha[o] = 1.0f - T_i;
+        last_out[o] = last;
+        count_out[o] = count;
+    }
+}
+
+void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
+{
+    if (a.T <= 0) return;
+    if (a.rgb_only)
+        k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.W / GS_TILE_SZ,
+                                              a.image, a.depth, a.acc_alpha, a.last, a.count);
+    else
+        k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.W / GS_TILE_SZ,
+                                               a.image, a.depth, a.acc_alpha, a.last, a.count);
+}

@@ -1,0 +1,183 @@
+"""GPU (-m gpu): the HIP operator, called through the C ABI, against the CPU oracle.
+
+Bar: integer arrays bit-exact; here the f32 forward products are
+bit-exact too (same IEEE operation sequence on both sides); gradients within 1e-4 of the
+tensor's max magnitude (float summation order differs: the reference itself uses unordered
+atomics, RAST:674-696)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import parity_util
+    return parity_util
+
+
+def _fwd_bwd(P, scene, q, t, band=3, hook=True, cfg_kw=None, seed=0):
+    got = {}
+    cfg = P.Rast.GaussianPointCloudRasterisationConfig(**(cfg_kw or {}))
+    module = P.Rast(cfg, backward_valid_point_hook=(lambda x: got.setdefault("hook", x)) if hook else None)
+    inp = P.make_input(scene, q, t, band)
+    ocfg = oracle.default_config(**{k: (int(v) if isinstance(v, bool) else v) for k, v in (cfg_kw or {}).items()})
+    f, feat_after = P.run_oracle(scene, q, t, ocfg)
+    outs = module(inp)
+    P.assert_forward_parity(module, inp, outs, f, feat_after)
+    image = outs[0]
+    rng = np.random.default_rng(seed)
+    target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
+    g_image = (2.0 * (image.detach() - target))
+    image.backward(g_image)
+    b = P.assert_backward_parity(module, inp, g_image.cpu().numpy(), f, band,
+                                 module.last_backward_extras if hook else None, ocfg)
+    return module, inp, f, b, got
+
+
+def test_cfg1_plumbing_full_parity(P):
+    """BASELINE config 1: 1e4 Gaussians, 256x256, SH degree 0."""
+    s = synth(**CONFIGS["cfg1_plumbing"])
+    q, t = view_pose()
+    module, inp, f, b, got = _fwd_bwd(P, s, q, t, band=0)
+    assert f.M == 10000 and f.K == 31202
+    h = got["hook"]                                   # reference tests :207-282 (shapes) + values
+    assert h.grad_point_in_camera.shape == (f.M, 3) and h.grad_pointfeatures_in_camera.shape == (f.M, 56)
+    assert h.grad_viewspace.shape == (f.M, 2) and h.magnitude_grad_viewspace.shape == (f.M,)
+    assert h.num_overlap_tiles.shape == (f.M,) and h.num_affected_pixels.shape == (f.M,)
+    ids = f.point_id_in_camera_list
+    assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), ids)
+    assert np.array_equal(h.grad_point_in_camera.cpu().numpy(), inp.point_cloud.grad.cpu().numpy()[ids])
+    assert np.array_equal(h.grad_pointfeatures_in_camera.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()[ids])
+    assert np.array_equal(h.num_overlap_tiles.cpu().numpy(), f.num_overlap_tiles)
+    assert np.array_equal(h.point_depth.cpu().numpy(), f.point_in_camera[:, 2])
+    assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), f.point_uv)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_small_scenes_pose_mask_objects(P, seed):
+    """Non-identity, non-unit pose quaternions, two objects, invalid rows, all SH bands."""
+    rng = np.random.default_rng(seed)
+    s = synth(3000, 160, 96, 0.08, sh_deg=3, seed=seed)
+    s.point_invalid_mask[rng.random(3000) < 0.1] = 1
+    s.point_object_id[:] = (rng.random(3000) < 0.3).astype(np.int32)
+    q = np.array([[0.02, 0.05, -0.01, 0.99], [-0.03, -0.02, 0.04, 1.02]], np.float32)
+    t = np.array([[0.1, -0.05, 0.2], [-0.2, 0.1, -0.1]], np.float32)
+    _fwd_bwd(P, s, q, t, band=int(seed % 4), seed=seed)
+
+
+def test_large_and_degenerate_splats(P):
+    """Splats far larger than the image, needle-like ones, opaque stacks that saturate pixels."""
+    s = synth(800, 128, 128, 0.5, sh_deg=3, seed=5)
+    s.point_cloud_features[:100, 4:7] = np.log(3.0)            # huge
+    s.point_cloud_features[100:200, 4] = np.log(2.0)           # needles
+    s.point_cloud_features[100:200, 5:7] = np.log(1e-4)
+    s.point_cloud_features[:, 7] = 6.0                         # nearly opaque -> saturation + 0.99 clamp
+    q, t = view_pose()
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t)
+    assert (f.pixel_accumulated_alpha > 0.9998).any()          # the T < 1e-4 stop is exercised
+
+
+@pytest.mark.parametrize("case", ["empty", "all_invalid", "behind", "one_point"])
+def test_edge_cases(P, case):
+    s = synth(64, 64, 48 if False else 64, 0.1, seed=3)
+    if case == "empty":
+        s.point_cloud = s.point_cloud[:0]; s.point_cloud_features = s.point_cloud_features[:0]
+        s.point_invalid_mask = s.point_invalid_mask[:0]; s.point_object_id = s.point_object_id[:0]
+    elif case == "all_invalid":
+        s.point_invalid_mask[:] = 1
+    elif case == "behind":
+        s.point_cloud[:, 2] = -s.point_cloud[:, 2]
+    elif case == "one_point":
+        s.point_invalid_mask[1:] = 1
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t)
+    f, feat_after = P.run_oracle(s, q, t)
+    outs = module(inp)
+    P.assert_forward_parity(module, inp, outs, f, feat_after)
+    outs[0].sum().backward()
+    if case != "one_point":
+        assert f.K == 0 and not outs[0].any() and not inp.point_cloud.grad.any()
+    else:
+        P.assert_backward_parity(module, inp, np.ones((s.height, s.width, 3), np.float32), f, 3)
+
+
+def test_rgb_only_and_no_grad(P):
+    """inference path: torch.no_grad + rgb_only (benchmark/inference_benchmark.py:110-156, RAST:781)."""
+    s = synth(5000, 256, 128, 0.05, seed=7)
+    q, t = view_pose(1, 3)
+    f, _ = P.run_oracle(s, q, t)
+    for rgb_only in (False, True):
+        module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig(rgb_only=rgb_only))
+        with torch.no_grad():
+            image, depth, count = module(P.make_input(s, q, t, requires_grad=False))
+        assert np.array_equal(image.cpu().numpy().view(np.uint32), f.rasterized_image.view(np.uint32))
+        if not rgb_only:
+            assert np.array_equal(count.cpu().numpy(), f.pixel_valid_point_count)
+
+
+def test_backward_is_bitwise_reproducible(P):
+    """No float atomics in this implementation: two runs give identical bits."""
+    s = synth(4000, 128, 128, 0.08, seed=11)
+    q, t = view_pose()
+    grads = []
+    for _ in range(2):
+        module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+        inp = P.make_input(s, q, t)
+        img = module(inp)[0]
+        (img * img).sum().backward()
+        grads.append((inp.point_cloud.grad.cpu().numpy().copy(), inp.point_cloud_features.grad.cpu().numpy().copy()))
+    assert np.array_equal(grads[0][0].view(np.uint32), grads[1][0].view(np.uint32))
+    assert np.array_equal(grads[0][1].view(np.uint32), grads[1][1].view(np.uint32))
+
+
+def test_argument_errors(P):
+    s = synth(16, 64, 64, 0.1)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t, requires_grad=False)
+    inp.camera_info.camera_width = 72                                   # RAST:1193
+    with pytest.raises(AssertionError):
+        module(inp)
+    inp = P.make_input(s, q, t, requires_grad=False)
+    inp.point_cloud_features = inp.point_cloud_features.double()
+    with pytest.raises(TypeError):
+        module(inp)
+    inp = P.make_input(s, q, t, requires_grad=False)
+    inp.point_cloud = inp.point_cloud.cpu()
+    with pytest.raises(ValueError):
+        module(inp)
+
+
+def test_training_loop_loss_decreases(P):
+    """reference tests :284-351 (test_backward_coverage), shortened: Adam on a 32x32 target."""
+    s = synth(256, 32, 32, 0.3, seed=2)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t)
+    pc, feat = inp.point_cloud.detach().requires_grad_(True), inp.point_cloud_features.detach().requires_grad_(True)
+    inp.point_cloud, inp.point_cloud_features = pc, feat
+    opt = torch.optim.Adam([pc, feat], lr=1e-3)
+    target = torch.rand(32, 32, 3, device=pc.device)
+    losses = []
+    for it in range(150):
+        inp.color_max_sh_band = it // 40
+        opt.zero_grad()
+        img = module(inp)[0]
+        loss = ((img - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+
+
+def test_cfg2_truck7k_scale_parity(P):
+    """BASELINE config 2: 2.3e5 Gaussians, 976x544, SH degree 3."""
+    s = synth(**CONFIGS["cfg2_truck7k"])
+    q, t = view_pose()
+    _fwd_bwd(P, s, q, t, band=3, hook=True)
