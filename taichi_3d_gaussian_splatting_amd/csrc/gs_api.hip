@@ -326,7 +326,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     if (!f->live || !f->bufs || f->ctx != c) return fail(GS_ERR_STATE, "gs_backward: frame is not live on this context");
     if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward: frame was not kept for backward");
     if (!grad_image || !acc_alpha || !last) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL image-sized input");
-    if (!out->grad_pointcloud || !out->grad_pointcloud_features)
+    if (sc->n_points > 0 && (!out->grad_pointcloud || !out->grad_pointcloud_features))
         return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: grad_pointcloud / grad_pointcloud_features are mandatory");
     if (sc->n_points != f->info.n_points || cam->camera_height != f->info.camera_height || cam->camera_width != f->info.camera_width)
         return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: scene/camera do not match the frame");
