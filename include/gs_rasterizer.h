@@ -169,10 +169,17 @@ int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
 /* Bytes of device memory the context currently owns (arena + frames). */
 int64_t gs_ctx_device_bytes(const gs_ctx* ctx);
 
-/* Time spent in the last forward/backward's dominant kernels is measured by the
- * caller with HIP events on `stream`; this returns the names of the kernels one
- * forward+backward launches, for profile post-processing. */
+/* Names of the kernels one forward+backward launches, comma separated; the position of a
+ * name is its kernel id in the two calls below. */
 const char* gs_kernel_names(void);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around the selected
+ * kernels (bit i of kernel_mask selects kernel id i; 0 switches timing off).  Stands in for the
+ * Taichi kernel profiler of the reference (GaussianPointTrainer.py:49,124,225-227). */
+int gs_profile_enable(gs_ctx* ctx, uint64_t kernel_mask);
+/* Waits for the recorded events, then copies accumulated milliseconds and launch counts of
+ * kernel ids [0, n) out; reset != 0 clears the accumulators. */
+int gs_profile_read(gs_ctx* ctx, double* total_ms, int64_t* launches, int32_t n, int32_t reset);
 
 #ifdef __cplusplus
 }

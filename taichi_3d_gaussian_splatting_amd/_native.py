@@ -71,7 +71,7 @@ EXPORTS = {
 # every symbol include/gs_rasterizer.h declares
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
-           "gs_ctx_device_bytes", "gs_kernel_names"]
+           "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read"]
 
 _lib = None
 
@@ -118,6 +118,8 @@ def lib():
                               _VP, _VP, _VP, _I32, C.POINTER(GsBackwardOut), _VP]
     L.gs_frame_release.argtypes = [_VP, _VP]
     L.gs_ctx_device_bytes.argtypes = [_VP]
+    L.gs_profile_enable.argtypes = [_VP, C.c_uint64]
+    L.gs_profile_read.argtypes = [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32, _I32]
     L.gs_ctx_device_bytes.restype = _I64
     if L.gs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH} has ABI {L.gs_abi_version()}, this package expects {ABI_VERSION}")

@@ -67,8 +67,38 @@ struct gs_frame {
     bool live = false;
 };
 
+struct GsProf {
+    uint64_t mask = 0;
+    struct Rec { int kid; hipEvent_t a, b; };
+    std::vector<Rec> recs;          // records in flight since the last read
+    std::vector<hipEvent_t> spare;  // recycled events
+    double total_ms[KID_COUNT_] = {};
+    int64_t launches[KID_COUNT_] = {};
+};
+
+int gs_prof_begin(GsProf* p, int kid, hipStream_t s)
+{
+    if (!p || !((p->mask >> kid) & 1ull)) return -1;
+    GsProf::Rec r; r.kid = kid;
+    hipEvent_t* ev[2] = { &r.a, &r.b };
+    for (hipEvent_t* e : ev) {
+        if (!p->spare.empty()) { *e = p->spare.back(); p->spare.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) return -1;
+    }
+    (void)hipEventRecord(r.a, s);
+    p->recs.push_back(r);
+    return (int)p->recs.size() - 1;
+}
+
+void gs_prof_end(GsProf* p, int rec, hipStream_t s)
+{
+    if (!p || rec < 0) return;
+    (void)hipEventRecord(p->recs[rec].b, s);
+}
+
 struct gs_ctx {
     int device = 0;
+    GsProf prof;
     std::mutex mu;
     int64_t device_bytes = 0;
     std::vector<FrameBufs*> pool;
@@ -115,8 +145,37 @@ extern "C" int gs_destroy(gs_ctx* c)
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
                       &c->counters, &c->partial };
     for (DevBuf* b : all) b->release(&c->device_bytes);
+    for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
     if (c->host_counters) (void)hipHostFree(c->host_counters);
     delete c;
+    return GS_OK;
+}
+
+extern "C" int gs_profile_enable(gs_ctx* c, uint64_t kernel_mask)
+{
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_profile_enable: ctx is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->prof.mask = kernel_mask;
+    return GS_OK;
+}
+
+extern "C" int gs_profile_read(gs_ctx* c, double* total_ms, int64_t* launches, int32_t n, int32_t reset)
+{
+    if (!c || !total_ms || !launches) return fail(GS_ERR_INVALID_ARGUMENT, "gs_profile_read: NULL argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    GsProf& p = c->prof;
+    for (GsProf::Rec& r : p.recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        p.total_ms[r.kid] += ms; p.launches[r.kid] += 1;
+        p.spare.push_back(r.a); p.spare.push_back(r.b);
+    }
+    p.recs.clear();
+    for (int i = 0; i < n && i < KID_COUNT_; ++i) { total_ms[i] = p.total_ms[i]; launches[i] = p.launches[i]; }
+    if (reset) for (int i = 0; i < KID_COUNT_; ++i) { p.total_ms[i] = 0.0; p.launches[i] = 0; }
     return GS_OK;
 }
 
@@ -208,6 +267,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
 
     GsProjectArgs pa{};
+    pa.prof = &c->prof;
     pa.point_cloud = sc->point_cloud; pa.features = sc->point_cloud_features; pa.invalid = sc->point_invalid_mask;
     pa.object_id = sc->point_object_id; pa.N = N; pa.q_pc = cam->q_pointcloud_camera; pa.t_pc = cam->t_pointcloud_camera;
     pa.n_objects = cam->n_objects; pa.Kmat = cam->camera_intrinsics; pa.H = H; pa.W = W;
@@ -241,6 +301,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     ENSURE(c->hist, 4 * hist_elems); ENSURE(c->scan_tmp, 4 * gs_scan_tmp_elems(hist_elems));
 
     GsBinArgs ba{};
+    ba.prof = &c->prof;
     ba.N = N; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
@@ -254,6 +315,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     HIP_TRY_F(hipGetLastError());
 
     GsBlendFwdArgs fa{};
+    fa.prof = &c->prof;
     fa.H = H; fa.W = W; fa.T = T; fa.rgb_only = cfg->rgb_only;
     fa.tile_start = ba.tile_start; fa.tile_end = ba.tile_end; fa.vals_sorted = f->vals_sorted;
     fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
@@ -344,6 +406,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     }
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
+    a.prof = &c->prof;
     a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = K;
     a.H = f->info.camera_height; a.W = f->info.camera_width; a.T = f->info.n_tiles;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_end.as<int32_t>(); a.vals_sorted = f->vals_sorted;

@@ -123,8 +123,24 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
     return v;
 }
 
+// ---- optional per-kernel timing with HIP events on the launch stream -------------
+// Kernel ids index the comma-separated list returned by gs_kernel_names().
+enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_SCAN_BLOCKS, KID_STORE_M, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
+                  KID_SORT_HIST, KID_SCAN_REDUCE, KID_SCAN_APPLY, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
+                  KID_BLEND_BWD, KID_BWD_POINTS, KID_COUNT_ };
+struct GsProf;
+int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
+void gs_prof_end(GsProf* p, int rec, hipStream_t s);
+#define GS_TIMED(prof, kid, stream, ...)                     \
+    do {                                                     \
+        int rec__ = gs_prof_begin((prof), (kid), (stream));  \
+        __VA_ARGS__;                                         \
+        gs_prof_end((prof), rec__, (stream));                \
+    } while (0)
+
 // ---- host-side launch wrappers (implemented in the k_*.hip files) --------------
 struct GsProjectArgs {
+    GsProf* prof;
     const float* point_cloud; float* features; const int8_t* invalid; const int32_t* object_id;
     int64_t N; const float* q_pc; const float* t_pc; int n_objects; const float* Kmat;
     int H, W; float near_plane, far_plane, depth_scale;
@@ -135,6 +151,7 @@ struct GsProjectArgs {
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
 
 struct GsBinArgs {
+    GsProf* prof;
     int64_t N; int M; uint32_t K; int H, W; float depth_scale; int depth_bits; int key_bits;
     const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
@@ -149,6 +166,7 @@ size_t gs_sort_hist_elems(uint32_t K);
 size_t gs_scan_tmp_elems(size_t n);
 
 struct GsBlendFwdArgs {
+    GsProf* prof;
     int H, W, T; int rgb_only;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
@@ -157,6 +175,7 @@ struct GsBlendFwdArgs {
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
 
 struct GsBackwardArgs {
+    GsProf* prof;
     int64_t N; int M; uint32_t K; int H, W, T;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;

@@ -76,12 +76,13 @@ static __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, u
 }
 
 // in -> out (may alias), n elements; tmp must hold 2*ceil(n/2048) u32.
-static inline void gs_scan_u32(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total, hipStream_t s)
+static inline void gs_scan_u32(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total, hipStream_t s,
+                               GsProf* prof = nullptr)
 {
     if (n <= 0) return;
-    if (n <= 8192) { k_scan_blocks<<<1, 1024, 0, s>>>(in, out, n, total); return; }
+    if (n <= 8192) { GS_TIMED(prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(in, out, n, total)); return; }
     int chunks = (n + GS_SCAN_CHUNK - 1) / GS_SCAN_CHUNK;
-    k_scan_reduce<<<chunks, 256, 0, s>>>(in, n, tmp);
-    k_scan_blocks<<<1, 1024, 0, s>>>(tmp, tmp + chunks, chunks, total);
-    k_scan_apply<<<chunks, 256, 0, s>>>(in, out, n, tmp + chunks);
+    GS_TIMED(prof, KID_SCAN_REDUCE, s, k_scan_reduce<<<chunks, 256, 0, s>>>(in, n, tmp));
+    GS_TIMED(prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(tmp, tmp + chunks, chunks, total));
+    GS_TIMED(prof, KID_SCAN_APPLY, s, k_scan_apply<<<chunks, 256, 0, s>>>(in, out, n, tmp + chunks));
 }

@@ -354,15 +354,15 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0)
-        k_blend_bwd<<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
-                                        a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.mag_image);
+        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd<<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
+                                                                       a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.mag_image));
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
-    k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.PD, a.point_cloud, a.features,
-                                    a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
-                                    a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
-                                    a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag);
+    GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.PD, a.point_cloud, a.features,
+                                                                    a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
+                                                                    a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
+                                                                    a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag));
 }

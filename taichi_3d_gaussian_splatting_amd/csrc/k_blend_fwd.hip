@@ -129,9 +129,9 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
     if (a.rgb_only)
-        k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.W / GS_TILE_SZ,
-                                              a.image, a.depth, a.acc_alpha, a.last, a.count);
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
+                                                                             a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count));
     else
-        k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.W / GS_TILE_SZ,
-                                               a.image, a.depth, a.acc_alpha, a.last, a.count);
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
+                                                                              a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count));
 }

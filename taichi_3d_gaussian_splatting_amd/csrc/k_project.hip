@@ -255,16 +255,17 @@ __global__ void k_store_M(const uint32_t* total, GsCounters* c) { c->M = (int32_
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
 {
     const int nb = (int)((a.N + 255) / 256);
-    k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters);
+    GS_TIMED(a.prof, KID_POSE, s, k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters));
     if (nb == 0) return;
-    k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.pose, a.N, a.W, a.H,
-                                a.near_plane, a.far_plane, a.mask, a.block_counts);
-    k_scan_blocks<<<1, 1024, 0, s>>>(reinterpret_cast<const uint32_t*>(a.block_counts),
-                                     reinterpret_cast<uint32_t*>(a.block_offsets), nb,
-                                     reinterpret_cast<uint32_t*>(&a.counters->reserved));
-    k_store_M<<<1, 1, 0, s>>>(reinterpret_cast<const uint32_t*>(&a.counters->reserved), a.counters);
-    k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_offsets, a.N, a.ids, a.cam_index);
-    k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
-                                 a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles, a.tile_block_sums, a.counters);
-    k_scan_blocks<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, &a.counters->K);
+    GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.pose, a.N, a.W, a.H,
+                                                            a.near_plane, a.far_plane, a.mask, a.block_counts));
+    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(reinterpret_cast<const uint32_t*>(a.block_counts),
+                                                                      reinterpret_cast<uint32_t*>(a.block_offsets), nb,
+                                                                      reinterpret_cast<uint32_t*>(&a.counters->reserved)));
+    GS_TIMED(a.prof, KID_STORE_M, s, k_store_M<<<1, 1, 0, s>>>(reinterpret_cast<const uint32_t*>(&a.counters->reserved), a.counters));
+    GS_TIMED(a.prof, KID_COMPACT, s, k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_offsets, a.N, a.ids, a.cam_index));
+    GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
+                                                              a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
+                                                              a.tile_block_sums, a.counters));
+    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, &a.counters->K));
 }
