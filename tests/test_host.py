@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the operator boundary -- pose helpers against the reference's own
+torch helpers (golden JSON), the synthetic generator, config semantics, argument validation."""
+import numpy as np
+import pytest
+import torch
+
+from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Rast
+from taichi_3d_gaussian_splatting_amd import utils as U
+from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose
+
+
+def test_inverse_se3_qt_matches_reference_helper(golden):
+    g = golden["inverse_SE3_qt"]                              # reference utils.py:426-432
+    qi, ti = U.inverse_SE3_qt_torch(torch.tensor(g["q"]), torch.tensor(g["t"]))
+    assert np.allclose(qi.numpy(), g["q_inv"], atol=1e-12) and np.allclose(ti.numpy(), g["t_inv"], atol=1e-12)
+
+
+def test_rotation_conversions_match_reference_helper(golden):
+    g = golden["rotation_matrix_to_quaternion"]               # reference utils.py:435-483, 596-632
+    R = torch.tensor(g["R"])
+    assert np.allclose(U.rotation_matrix_to_quaternion_torch(R).numpy(), g["q"], atol=1e-9)
+    q = torch.tensor(g["q"])
+    assert np.allclose(U.quaternion_to_rotation_matrix_torch(q).numpy(), g["R"], atol=1e-9)
+    T = torch.eye(4, dtype=torch.float64).repeat(R.shape[0], 1, 1)
+    T[:, :3, :3] = R
+    T[:, :3, 3] = torch.arange(3, dtype=torch.float64)
+    q2, t2 = U.SE3_to_quaternion_and_translation_torch(T)
+    assert np.allclose(q2.numpy(), g["q"], atol=1e-9) and np.allclose(t2.numpy(), [[0, 1, 2]] * R.shape[0])
+
+
+def test_pose_inverse_round_trip():
+    """reference tests/utils_test.py:139-157 pattern: inverse of the inverse is the pose."""
+    rng = np.random.default_rng(0)
+    q = torch.tensor(rng.normal(size=(50, 4)))
+    q = q / q.norm(dim=-1, keepdim=True)
+    t = torch.tensor(rng.normal(size=(50, 3)))
+    qi, ti = U.inverse_SE3_qt_torch(q, t)
+    q2, t2 = U.inverse_SE3_qt_torch(qi, ti)
+    assert torch.allclose(q2, q) and torch.allclose(t2, t, atol=1e-12)
+    Rm, Ri = U.quaternion_to_rotation_matrix_torch(q), U.quaternion_to_rotation_matrix_torch(qi)
+    assert torch.allclose(Rm @ Ri, torch.eye(3, dtype=torch.float64).expand(50, 3, 3), atol=1e-12)
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = synth(**CONFIGS["cfg1_plumbing"]), synth(**CONFIGS["cfg1_plumbing"])
+    assert np.array_equal(a.point_cloud, b.point_cloud) and np.array_equal(a.point_cloud_features, b.point_cloud_features)
+    assert a.point_cloud.shape == (10000, 3) and a.point_cloud_features.shape == (10000, 56)
+    assert a.point_cloud.dtype == np.float32 and a.point_invalid_mask.dtype == np.int8 and a.point_object_id.dtype == np.int32
+    assert not a.point_cloud_features[:, 9:24].any()              # sh_deg 0: only DC
+    assert np.allclose(np.linalg.norm(a.point_cloud_features[:, :4], axis=1), 1, atol=1e-6)
+    q, t = view_pose(0, 1)
+    assert np.array_equal(q, [[0, 0, 0, 1]]) and not t.any()
+    qs = [view_pose(i, 8)[0] for i in range(8)]
+    assert np.allclose(qs[0][0, 1], -qs[7][0, 1])                 # symmetric fan of views
+
+
+def test_config_matches_reference_semantics():
+    """RAST:776-786: four dataclass fields; the five grad factors are plain class attributes."""
+    import dataclasses
+    Cfg = Rast.GaussianPointCloudRasterisationConfig
+    assert [f.name for f in dataclasses.fields(Cfg)] == ["near_plane", "far_plane", "depth_to_sort_key_scale", "rgb_only"]
+    c = Cfg()
+    assert (c.near_plane, c.far_plane, c.depth_to_sort_key_scale, c.rgb_only) == (0.8, 1000.0, 100.0, False)
+    assert (c.grad_color_factor, c.grad_high_order_color_factor, c.grad_s_factor, c.grad_q_factor, c.grad_alpha_factor) == (5.0, 1.0, 0.5, 1.0, 20.0)
+    Inp = Rast.GaussianPointCloudRasterisationInput
+    assert [f.name for f in dataclasses.fields(Inp)] == ["point_cloud", "point_cloud_features", "point_object_id", "point_invalid_mask",
+                                                         "camera_info", "q_pointcloud_camera", "t_pointcloud_camera", "color_max_sh_band"]
+    assert dataclasses.fields(Inp)[-1].default == 2
+    Hook = Rast.BackwardValidPointHookInput
+    assert [f.name for f in dataclasses.fields(Hook)] == [
+        "point_id_in_camera_list", "grad_point_in_camera", "grad_pointfeatures_in_camera", "grad_viewspace",
+        "magnitude_grad_viewspace", "magnitude_grad_viewspace_on_image", "num_overlap_tiles", "num_affected_pixels",
+        "point_depth", "point_uv_in_camera"]
+
+
+def test_operator_rejects_bad_arguments_before_touching_the_gpu():
+    s = synth(8, 32, 32, 0.1)
+    q, t = view_pose()
+    m = Rast(Rast.GaussianPointCloudRasterisationConfig())
+    mk = lambda **kw: Rast.GaussianPointCloudRasterisationInput(**{**dict(
+        point_cloud=torch.tensor(s.point_cloud), point_cloud_features=torch.tensor(s.point_cloud_features),
+        point_object_id=torch.tensor(s.point_object_id), point_invalid_mask=torch.tensor(s.point_invalid_mask),
+        camera_info=CameraInfo(torch.tensor(s.camera_intrinsics), 32, 32, 0),
+        q_pointcloud_camera=torch.tensor(q), t_pointcloud_camera=torch.tensor(t)), **kw})
+    with pytest.raises(AssertionError):                            # RAST:1193-1194
+        m(mk(camera_info=CameraInfo(torch.tensor(s.camera_intrinsics), 32, 40, 0)))
+    with pytest.raises(ValueError, match="GPU"):                   # CPU tensors: no silent CPU path
+        m(mk())
+    with pytest.raises(TypeError):
+        m(mk(point_cloud=torch.tensor(s.point_cloud).double()))
