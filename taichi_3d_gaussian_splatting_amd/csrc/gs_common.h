@@ -37,8 +37,7 @@ struct GsCounters {
 // ---- device math -------------------------------------------------------------
 __device__ __forceinline__ float gs_expf(float x)
 {
-    if (x < -86.0f) x = -86.0f;
-    if (x > 88.0f) x = 88.0f;
+    x = __builtin_amdgcn_fmed3f(x, -86.0f, 88.0f);   // clamp (one v_med3_f32); same value as the two compares of the oracle
     float fx = x * 1.44269504088896341f;
     float n = (fx + 12582912.0f) - 12582912.0f;      // round to nearest even
     float r = __builtin_fmaf(n, -0.693359375f, x);
@@ -107,6 +106,38 @@ __device__ __forceinline__ float gs_wave_sum_row3(float v)
     v += gs_dpp<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
     v += gs_dpp<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
     return v;
+}
+
+// The same reduction for 11 values at once, written as v_add_f32_dpp so that every step is ONE
+// instruction per value (hipcc lowers the builtin form to v_mov_dpp + add, and to three
+// instructions for the row_bcast steps).  A DPP source written by the previous VALU instruction
+// needs two wait states: each step starts with s_nop 1; inside a step the eleven registers
+// are independent and eleven instructions apart from their next use.
+#define GS_DPP11(ctrl)                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                      \
+                 "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %9, %9, %9 " ctrl "\n\t"                                            \
+                 "v_add_f32_dpp %10, %10, %10 " ctrl "\n\t"                                         \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), \
+                   "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]))
+
+__device__ __forceinline__ void gs_wave_sum11_row3(float (&v)[11])
+{
+    GS_DPP11("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    GS_DPP11("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    GS_DPP11("row_half_mirror row_mask:0xf bank_mask:0xf");
+    GS_DPP11("row_mirror row_mask:0xf bank_mask:0xf");
+    GS_DPP11("row_bcast:15 row_mask:0xa bank_mask:0xf");     // rows 1,3 += lane 15 of rows 0,2; rows 0,2 untouched
+    GS_DPP11("row_bcast:31 row_mask:0xc bank_mask:0xf");     // rows 2,3 += lane 31
+    asm volatile("s_nop 1");
 }
 
 __device__ __forceinline__ int gs_wave_sum_i(int v)

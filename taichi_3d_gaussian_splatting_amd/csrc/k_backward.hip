@@ -115,33 +115,35 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const int32_t* __restrict__ t
                     const bool use = in_range && prod_alpha >= GS_ALPHA_EPS;      // RAST:634
                     if (!__any(use)) continue;
                     float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
-                    float one_m = 1.0f - alpha;
-                    float inv = 1.0f / one_m;
-                    float Tn = T_i / one_m;                                       // RAST:643
-                    float d_rgb = alpha * Tn;
+                    float one_m = 1.0f - alpha;                                   // in [0.01, 0.9961]
+                    // T / (1 - alpha), RAST:643: reciprocal + one residual correction (<= 1 ulp, no div_scale/fixup)
+                    float inv = __builtin_amdgcn_rcpf(one_m);
+                    float Tn = T_i * inv;
+                    Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, T_i), inv, Tn);
                     float ag = (c4.x * Tn - w0 * inv) * gr + (c4.y * Tn - w1 * inv) * gg + (c4.z * Tn - w2 * inv) * gb;  // RAST:653-657
+                    // masking three factors zeroes all eleven sums of the lanes that do not contribute
+                    ag = use ? ag : 0.0f;
+                    float d_rgb = use ? alpha * Tn : 0.0f;                         // RAST:649
                     float gag = ag * apt;                                         // RAST:662
-                    float hg = 0.5f * g * gag;
-                    float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);           // RAST:664-665
+                    float hg = 0.5f * g * gag;                                    // d p / d cov = 0.5 p (S^-1 d)(S^-1 d)^T
                     float v[11];
-                    v[0] = use ? vs0 : 0.0f;
-                    v[1] = use ? vs1 : 0.0f;
-                    v[2] = use ? hg * cix * cix : 0.0f;                           // d p / d cov = 0.5 p (S^-1 d)(S^-1 d)^T
-                    v[3] = use ? hg * cix * ciy : 0.0f;
-                    v[4] = use ? hg * ciy * ciy : 0.0f;
-                    v[5] = use ? d_rgb * gr : 0.0f;                               // RAST:649-650
-                    v[6] = use ? d_rgb * gg : 0.0f;
-                    v[7] = use ? d_rgb * gb : 0.0f;
-                    v[8] = use ? (ag * g) * (1.0f - apt) * apt : 0.0f;            // RAST:658-661
-                    v[9] = use ? __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1) : 0.0f;   // RAST:691-694
+                    v[0] = gag * (g * cix);                                       // RAST:664-665
+                    v[1] = gag * (g * ciy);
+                    v[2] = hg * cix * cix;
+                    v[3] = hg * cix * ciy;
+                    v[4] = hg * ciy * ciy;
+                    v[5] = d_rgb * gr;                                            // RAST:650
+                    v[6] = d_rgb * gg;
+                    v[7] = d_rgb * gb;
+                    v[8] = (ag * g) * (1.0f - apt) * apt;                         // RAST:658-661
+                    v[9] = __builtin_amdgcn_sqrtf(v[0] * v[0] + v[1] * v[1]);     // RAST:691-694
                     v[10] = use ? 1.0f : 0.0f;                                    // RAST:695-696
                     if (use) {
                         T_i = Tn;
                         w0 += c4.x * alpha * Tn; w1 += c4.y * alpha * Tn; w2 += c4.z * alpha * Tn;   // RAST:656
-                        tot0 += fabsf(vs0); tot1 += fabsf(vs1);                   // RAST:666-667
                     }
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) v[k] = gs_wave_sum_row3(v[k]);
+                    tot0 += fabsf(v[0]); tot1 += fabsf(v[1]);                     // RAST:666-667
+                    gs_wave_sum11_row3(v);
                     if (lane == 63) {
                         acc[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
                         acc[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
