@@ -105,7 +105,7 @@ struct gs_ctx {
     std::vector<gs_frame*> frames;      // every handle ever issued (recycled)
     gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
-    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial;
+    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited;
     GsCounters* host_counters = nullptr;   // pinned
 };
 
@@ -115,7 +115,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* gs_kernel_names(void)
 {
     return "k_pose_prepare,k_filter,k_scan_blocks,k_store_M,k_compact,k_project,k_keygen,k_sort_hist,k_scan_reduce,"
-           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd,k_bwd_points";
+           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points";
 }
 
 extern "C" int gs_create(int32_t device, gs_ctx** out)
@@ -143,7 +143,7 @@ extern "C" int gs_destroy(gs_ctx* c)
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
     for (gs_frame* f : c->frames) delete f;
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
-                      &c->counters, &c->partial };
+                      &c->counters, &c->partial, &c->visited };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
@@ -403,6 +403,8 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     {
         hipError_t e = c->partial.ensure((size_t)(K > 0 ? K : 1) * 12 * sizeof(float), &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: partial-sum buffer");
+        e = c->visited.ensure((size_t)(K > 0 ? K : 1), &c->device_bytes);
+        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: visited buffer");
     }
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
@@ -415,6 +417,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.ids = B.ids.as<int32_t>(); a.cam_index = B.cam_index.as<int32_t>();
     a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;
     a.partial = c->partial.as<float>();
+    a.visited = c->visited.as<uint8_t>();
     a.point_cloud = sc->point_cloud; a.features = sc->point_cloud_features; a.object_id = sc->point_object_id;
     a.Kmat = cam->camera_intrinsics; a.pose = B.pose.as<GsPose>();
     a.sh_band = sh_band; a.f_color = cfg->grad_color_factor; a.f_high = cfg->grad_high_order_color_factor;

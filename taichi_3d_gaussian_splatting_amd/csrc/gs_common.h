@@ -213,6 +213,7 @@ struct GsBackwardArgs {
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;
     float* partial;                 // (K,12) per (point,tile) sums in slot order
+    uint8_t* visited;               // (K) 1 where the row of `partial` was written this backward
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
     float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;

@@ -1,20 +1,21 @@
 // k_backward.hip -- gaussian_point_rasterisation_backward, RAST:488-772, plus the torch
 // post-processing RAST:1102-1140, as two kernels and NO global atomics:
 //
-//   k_blend_bwd   loop 1 (RAST:531-705).  One workgroup per tile, each wave owns an 8x8
-//                 quadrant and walks the list back to front.  The 11 per-contribution
-//                 quantities the reference sends to HBM with ti.atomic_add (RAST:674-696) are
-//                 summed over the wave's 64 pixels with DPP, combined over the 4 waves in LDS,
-//                 and stored ONCE per (point, tile) pair as a 12-float row of `partial`, at the
-//                 pair's pre-sort slot (offsets[p] + position of the tile in p's tile box), so
-//                 all rows of a point are contiguous.
-//   k_bwd_points  loop 2 (RAST:708-772) over all N rows: sums a point's rows in slot order
-//                 (deterministic), chains the Jacobians (GP3D:132-159, 237-331, 351-373),
+//   k_blend_bwd_tile  loop 1 (RAST:531-705).  One wave per tile walks the tile's list back to
+//                 front.  The 11 per-contribution quantities the reference sends to HBM with
+//                 ti.atomic_add (RAST:674-696) are summed over the tile's 256 pixels in
+//                 registers + DPP and stored ONCE per (point, tile) pair as a 12-float row of
+//                 `partial`, at the pair's pre-sort slot (offsets[p] + position of the tile in
+//                 p's tile box), so all rows of a point are contiguous; a byte of `visited`
+//                 marks the rows that were written.
+//   k_bwd_points  loop 2 (RAST:708-772) over all N rows: sums a point's visited rows in slot
+//                 order (deterministic), chains the Jacobians (GP3D:132-159, 237-331, 351-373),
 //                 applies band masks and grad factors (RAST:1102-1125, 1167-1182) and writes
 //                 every output row exactly once (zero for rows outside the frustum), including
 //                 the BackwardValidPointHookInput gathers (RAST:1128-1140).
-// k_blend_bwd is VALU/LDS bound, k_bwd_points HBM bound: see DESIGN.md.
+// k_blend_bwd_tile is VALU/latency bound, k_bwd_points HBM bound: see DESIGN.md.
 #include "gs_common.h"
+#include <cstdlib>
 
 #define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count | pad
 
@@ -50,138 +51,154 @@ __device__ __forceinline__ bool gs_cull_b(float4 A, float4 B, float4 C, float rx
     return pd && (-0.5f * qmin + slack < C.w);
 }
 
-__global__ __launch_bounds__(256) void k_blend_bwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
-                                                   const int32_t* __restrict__ sorted_vals,
-                                                   const float4* __restrict__ PA, const float4* __restrict__ PB,
-                                                   const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
-                                                   const uint32_t* __restrict__ offsets,
-                                                   const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
-                                                   const int32_t* __restrict__ last_in, int W, int tiles_x,
-                                                   float* __restrict__ partial, float* __restrict__ mag_image)
+// ---------------------------------------------------------------------------------
+// Loop 1: ONE WAVE PER TILE, four pixels per lane (one per 8x8 quadrant).
+//   * no __syncthreads, no cross-wave combine: the wave sums a splat's contributions over its
+//     own 256 pixels (in-lane over the quadrants, then one DPP reduction) and lane 63 stores the
+//     48-byte row itself;
+//   * the four quadrants give every lane four independent T/w recurrences to interleave;
+//   * culling stays per quadrant: each lane tests its splat against the four 8x8 rectangles,
+//     four ballots, and a quadrant body runs only for the (splat, quadrant) pairs that survive.
+// Pairs that are never visited (beyond every pixel's last index -- about three quarters of a
+// saturated tile's list -- or culled in all four quadrants) cost nothing: their rows are not
+// written and their `visited` byte stays 0 (the array is cleared by a memset per backward).
+struct QuadState { float T, w0, w1, w2, gr, gg, gb, tot0, tot1; int last; };
+
+__global__ __launch_bounds__(64) void k_blend_bwd_tile(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                       const int32_t* __restrict__ sorted_vals,
+                                                       const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                       const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
+                                                       const int32_t* __restrict__ last_in, int W, int tiles_x,
+                                                       float* __restrict__ partial, uint8_t* __restrict__ visited, float* __restrict__ mag_image)
 {
-    __shared__ float4 sA[4][64], sB[4][64], sC[4][64];
-    __shared__ float4 acc[4][64][3];
-    __shared__ unsigned long long hit[4];
-    __shared__ int wmax[4];
+    __shared__ float4 sA[64], sB[64], sC[64];
     const int tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
-    const int qx = tile_u * 16 + (wave & 1) * 8, qy = tile_v * 16 + (wave >> 1) * 8;
-    const int pixel_u = qx + (lane & 7), pixel_v = qy + (lane >> 3);
-    const float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
-    const float rx0 = (float)qx + 0.5f, ry0 = (float)qy + 0.5f;
     const int start = tile_start[tile], end = tile_end[tile];
-    const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
-
-    const int last = last_in[o];                                   // RAST:558
-    float T_i = 1.0f - acc_alpha[o];                               // RAST:559-560
-    float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
-    const float gr = grad_image[3 * o], gg = grad_image[3 * o + 1], gb = grad_image[3 * o + 2];
-    float tot0 = 0.0f, tot1 = 0.0f;
-
-    const int wave_last = gs_wave_max_i(last);
-    if (lane == 0) wmax[wave] = wave_last;
-    __syncthreads();
-    const int tile_last = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-
-    for (int hi = end; hi > start; hi -= 64) {
-        const int lo = max(start, hi - 64);
-        unsigned long long my_hits = 0ull;
-        if (lo < tile_last && lo < wave_last) {
-            const int i = lo + lane;
-            const bool valid = i < hi && i < wave_last;
-            const int p = (i < hi) ? sorted_vals[i] : 0;
-            float4 A = PA[p], B = PB[p], C = PC[p];
-            bool keep = valid && !gs_cull_b(A, B, C, rx0, ry0);
-            unsigned long long mask = __ballot(keep);
-            if (mask) {
-                sA[wave][lane] = A; sB[wave][lane] = B; sC[wave][lane] = C;
-                __builtin_amdgcn_wave_barrier();
-                while (mask) {
-                    const int j = 63 - __builtin_clzll(mask);             // back to front, RAST:605-608
-                    mask &= ~(1ull << j);
-                    const float4 a4 = sA[wave][j], b4 = sB[wave][j], c4 = sC[wave][j];
-                    const float a = a4.z, b = a4.w, c = b4.x;
-                    // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
-                    float dx = px - a4.x, dy = py - a4.y;
-                    float cix = a * dx + b * dy, ciy = b * dx + c * dy;
-                    float quad = dx * cix + dy * ciy;
-                    float exponent = -0.5f * quad;
-                    const bool in_range = (lo + j) < last;                // RAST:609-610
-                    if (!__any(in_range && !(exponent + 0.02f < c4.w))) continue;
-                    float g = gs_expf(exponent) * b4.y;
-                    float apt = b4.z;
-                    float prod_alpha = g * apt;
-                    const bool use = in_range && prod_alpha >= GS_ALPHA_EPS;      // RAST:634
-                    if (!__any(use)) continue;
-                    float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
-                    float one_m = 1.0f - alpha;                                   // in [0.01, 0.9961]
-                    // T / (1 - alpha), RAST:643: reciprocal + one residual correction (<= 1 ulp, no div_scale/fixup)
-                    float inv = __builtin_amdgcn_rcpf(one_m);
-                    float Tn = T_i * inv;
-                    Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, T_i), inv, Tn);
-                    float ag = (c4.x * Tn - w0 * inv) * gr + (c4.y * Tn - w1 * inv) * gg + (c4.z * Tn - w2 * inv) * gb;  // RAST:653-657
-                    // masking three factors zeroes all eleven sums of the lanes that do not contribute
-                    ag = use ? ag : 0.0f;
-                    float d_rgb = use ? alpha * Tn : 0.0f;                         // RAST:649
-                    float gag = ag * apt;                                         // RAST:662
-                    float hg = 0.5f * g * gag;                                    // d p / d cov = 0.5 p (S^-1 d)(S^-1 d)^T
-                    float v[11];
-                    v[0] = gag * (g * cix);                                       // RAST:664-665
-                    v[1] = gag * (g * ciy);
-                    v[2] = hg * cix * cix;
-                    v[3] = hg * cix * ciy;
-                    v[4] = hg * ciy * ciy;
-                    v[5] = d_rgb * gr;                                            // RAST:650
-                    v[6] = d_rgb * gg;
-                    v[7] = d_rgb * gb;
-                    v[8] = (ag * g) * (1.0f - apt) * apt;                         // RAST:658-661
-                    v[9] = __builtin_amdgcn_sqrtf(v[0] * v[0] + v[1] * v[1]);     // RAST:691-694
-                    v[10] = use ? 1.0f : 0.0f;                                    // RAST:695-696
-                    if (use) {
-                        T_i = Tn;
-                        w0 += c4.x * alpha * Tn; w1 += c4.y * alpha * Tn; w2 += c4.z * alpha * Tn;   // RAST:656
-                    }
-                    tot0 += fabsf(v[0]); tot1 += fabsf(v[1]);                     // RAST:666-667
-                    gs_wave_sum11_row3(v);
-                    if (lane == 63) {
-                        acc[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
-                        acc[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
-                        acc[wave][j][2] = make_float4(v[8], v[9], v[10], 0.0f);
-                    }
-                    my_hits |= 1ull << j;
-                }
-            }
-        }
-        if (lane == 0) hit[wave] = my_hits;
-        __syncthreads();
-        {   // one 12-float row per (point, tile) pair, stored at the pair's pre-sort slot
-            const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
-            const int i = lo + e;
-            if (i < hi) {
-                const int p = sorted_vals[i];
-                const ushort4 bx = boxes[p];
-                const uint32_t slot = offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z));
-                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    const int lx = lane & 7, ly = lane >> 3;
+    QuadState Q[4];
+    int qlast[4];
+    float rx0[4], ry0[4];
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if ((hit[w] >> e) & 1ull) {
-                        const float* r = reinterpret_cast<const float*>(&acc[w][e][0]) + part * 3;
-                        s0 += r[0]; s1 += r[1]; s2 += r[2];
+    for (int q = 0; q < 4; ++q) {
+        const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
+        const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
+        Q[q].last = last_in[o];                                     // RAST:558
+        Q[q].T = 1.0f - acc_alpha[o];                               // RAST:559-560
+        Q[q].w0 = Q[q].w1 = Q[q].w2 = 0.0f;
+        Q[q].gr = grad_image[3 * o]; Q[q].gg = grad_image[3 * o + 1]; Q[q].gb = grad_image[3 * o + 2];
+        Q[q].tot0 = Q[q].tot1 = 0.0f;
+        qlast[q] = gs_wave_max_i(Q[q].last);
+        rx0[q] = (float)(tile_u * 16 + (q & 1) * 8) + 0.5f;
+        ry0[q] = (float)(tile_v * 16 + (q >> 1) * 8) + 0.5f;
+    }
+    const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
+    const float px_lo = (float)(tile_u * 16 + lx) + 0.5f, py_lo = (float)(tile_v * 16 + ly) + 0.5f;
+
+    // entries at or beyond tile_last are dead for every pixel of the tile (RAST:609-610)
+    for (int hi = min(end, tile_last); hi > start; hi -= 64) {
+        const int lo = max(start, hi - 64);
+        const int i = lo + lane;
+        const bool valid = i < hi;
+        const int p = valid ? sorted_vals[i] : 0;
+        {
+            const float4 A = PA[p], B = PB[p], C = PC[p];
+            unsigned long long mq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mq[q] = __ballot(valid && i < qlast[q] && !gs_cull_b(A, B, C, rx0[q], ry0[q]));
+            unsigned long long U = mq[0] | mq[1] | mq[2] | mq[3];
+            if (U) {
+                uint32_t slot = 0;
+                if ((U >> lane) & 1ull) {                                     // pre-sort slot of this (point, tile) pair
+                    const ushort4 bx = boxes[p];
+                    slot = offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z));
+                }
+                sA[lane] = A; sB[lane] = B; sC[lane] = C;
+                __builtin_amdgcn_wave_barrier();
+                while (U) {
+                    const int j = 63 - __builtin_clzll(U);                    // back to front, RAST:605-608
+                    U &= ~(1ull << j);
+                    const float4 a4 = sA[j], b4 = sB[j], c4 = sC[j];
+                    const float a = a4.z, b = a4.w, c = b4.x, apt = b4.z;
+                    float v[11];
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) v[k] = 0.0f;
+                    bool any_use = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!((mq[q] >> j) & 1ull)) continue;                 // wave-uniform
+                        // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
+                        const float dx = (px_lo + (float)((q & 1) * 8)) - a4.x, dy = (py_lo + (float)((q >> 1) * 8)) - a4.y;
+                        const float cix = a * dx + b * dy, ciy = b * dx + c * dy;
+                        const float exponent = -0.5f * (dx * cix + dy * ciy);
+                        const bool in_range = (lo + j) < Q[q].last;              // RAST:609-610
+                        if (!__any(in_range && !(exponent + 0.02f < c4.w))) continue;
+                        const float g = gs_expf(exponent) * b4.y;
+                        const float prod_alpha = g * apt;
+                        const bool use = in_range && prod_alpha >= GS_ALPHA_EPS; // RAST:634
+                        if (!__any(use)) continue;
+                        any_use = true;
+                        const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
+                        const float one_m = 1.0f - alpha;
+                        const float inv = __builtin_amdgcn_rcpf(one_m);
+                        float Tn = Q[q].T * inv;                                  // RAST:643 (rcp + one correction)
+                        Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[q].T), inv, Tn);
+                        float ag = (c4.x * Tn - Q[q].w0 * inv) * Q[q].gr + (c4.y * Tn - Q[q].w1 * inv) * Q[q].gg +
+                                   (c4.z * Tn - Q[q].w2 * inv) * Q[q].gb;        // RAST:653-657
+                        ag = use ? ag : 0.0f;
+                        const float d_rgb = use ? alpha * Tn : 0.0f;            // RAST:649
+                        const float gag = ag * apt;                             // RAST:662
+                        const float hg = 0.5f * g * gag;
+                        const float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);   // RAST:664-665
+                        v[0] += vs0; v[1] += vs1;
+                        v[2] = __builtin_fmaf(hg * cix, cix, v[2]);
+                        v[3] = __builtin_fmaf(hg * cix, ciy, v[3]);
+                        v[4] = __builtin_fmaf(hg * ciy, ciy, v[4]);
+                        v[5] = __builtin_fmaf(d_rgb, Q[q].gr, v[5]);             // RAST:650
+                        v[6] = __builtin_fmaf(d_rgb, Q[q].gg, v[6]);
+                        v[7] = __builtin_fmaf(d_rgb, Q[q].gb, v[7]);
+                        v[8] = __builtin_fmaf((ag * g) * (1.0f - apt), apt, v[8]);   // RAST:658-661
+                        v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
+                        v[10] += use ? 1.0f : 0.0f;                              // RAST:695-696
+                        if (use) {
+                            Q[q].T = Tn;
+                            Q[q].w0 += c4.x * alpha * Tn; Q[q].w1 += c4.y * alpha * Tn; Q[q].w2 += c4.z * alpha * Tn;   // RAST:656
+                        }
+                        Q[q].tot0 += fabsf(vs0); Q[q].tot1 += fabsf(vs1);        // RAST:666-667
                     }
-                float* dst = partial + (size_t)slot * PW + part * 3;
-                dst[0] = s0; dst[1] = s1; dst[2] = s2;
+                    if (!any_use) continue;
+                    gs_wave_sum11_row3(v);
+                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+                    if (lane == 63) {
+                        float4* dst = reinterpret_cast<float4*>(partial + (size_t)sj * PW);
+                        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                        dst[2] = make_float4(v[8], v[9], v[10], 0.0f);
+                        visited[sj] = 1;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
     }
-    if (mag_image) { mag_image[2 * o] = tot0; mag_image[2 * o + 1] = tot1; }   // RAST:700-704
+    if (mag_image) {                                                            // RAST:700-704
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
+            const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
+            mag_image[2 * o] = Q[q].tot0; mag_image[2 * o + 1] = Q[q].tot1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bwd_points(
     int64_t N, const int32_t* __restrict__ cam_index, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
-    const float* __restrict__ partial, const float4* __restrict__ PD,
+    const float* __restrict__ partial, const uint8_t* __restrict__ visited, const float4* __restrict__ PD,
     const float* __restrict__ pc, const float* __restrict__ feat, const int32_t* __restrict__ obj,
     const float* __restrict__ Kmat, const GsPose* __restrict__ pose,
     int keep, float f_color, float f_high, float f_s, float f_q, float f_alpha,
@@ -206,9 +223,12 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 #pragma unroll
     for (int k = 0; k < PW; ++k) s[k] = 0.0f;
     {
-        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)offsets[m] * PW);
+        const uint32_t off = offsets[m];
+        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)off * PW);
+        const uint8_t* vis = visited + off;
         const int cnt = ntiles[m];
         for (int i = 0; i < cnt; ++i) {
+            if (!vis[i]) continue;                                  // pair never reached by any pixel: contributes nothing
             float4 r0 = rows[3 * i], r1 = rows[3 * i + 1], r2 = rows[3 * i + 2];
             s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
             s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
@@ -355,15 +375,18 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
-    if (a.T > 0 && a.K > 0)
-        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd<<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
-                                                                       a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.mag_image));
+    if (a.T > 0 && a.K > 0) {
+        (void)hipMemsetAsync(a.visited, 0, (size_t)a.K, s);
+        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<<<a.T, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
+                                                                           a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial,
+                                                                           a.visited, a.mag_image));
+    }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
-    GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.PD, a.point_cloud, a.features,
+    GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.visited, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
                                                                     a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
                                                                     a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag));
