@@ -64,7 +64,7 @@ __device__ __forceinline__ bool gs_cull_b(float4 A, float4 B, float4 C, float rx
 // written and their `visited` byte stays 0 (the array is cleared by a memset per backward).
 struct QuadState { float T, w0, w1, w2, gr, gg, gb, tot0, tot1; int last; };
 
-__global__ __launch_bounds__(64) void k_blend_bwd_tile(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+__global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                        const int32_t* __restrict__ sorted_vals,
                                                        const float4* __restrict__ PA, const float4* __restrict__ PB,
                                                        const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
@@ -137,38 +137,46 @@ __global__ __launch_bounds__(64) void k_blend_bwd_tile(const int32_t* __restrict
                         const float exponent = -0.5f * (dx * cix + dy * ciy);
                         const bool in_range = (lo + j) < Q[q].last;              // RAST:609-610
                         if (!__any(in_range && !(exponent + 0.02f < c4.w))) continue;
-                        const float g = gs_expf(exponent) * b4.y;
-                        const float prod_alpha = g * apt;
+                        // exp: the hardware v_exp_f32 (1 ulp) unless some lane sits within 1e-5 (relative) of the
+                        // 1/255 threshold, where the reference polynomial decides (same decisions as the oracle)
+                        float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
+                        float prod_alpha = g * apt;
+                        if (__any(in_range && fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f)) {
+                            g = gs_expf(exponent) * b4.y;
+                            prod_alpha = g * apt;
+                        }
                         const bool use = in_range && prod_alpha >= GS_ALPHA_EPS; // RAST:634
                         if (!__any(use)) continue;
                         any_use = true;
-                        const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
-                        const float one_m = 1.0f - alpha;
-                        const float inv = __builtin_amdgcn_rcpf(one_m);
-                        float Tn = Q[q].T * inv;                                  // RAST:643 (rcp + one correction)
-                        Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[q].T), inv, Tn);
-                        float ag = (c4.x * Tn - Q[q].w0 * inv) * Q[q].gr + (c4.y * Tn - Q[q].w1 * inv) * Q[q].gg +
-                                   (c4.z * Tn - Q[q].w2 * inv) * Q[q].gb;        // RAST:653-657
-                        ag = use ? ag : 0.0f;
-                        const float d_rgb = use ? alpha * Tn : 0.0f;            // RAST:649
-                        const float gag = ag * apt;                             // RAST:662
-                        const float hg = 0.5f * g * gag;
-                        const float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);   // RAST:664-665
-                        v[0] += vs0; v[1] += vs1;
-                        v[2] = __builtin_fmaf(hg * cix, cix, v[2]);
-                        v[3] = __builtin_fmaf(hg * cix, ciy, v[3]);
-                        v[4] = __builtin_fmaf(hg * ciy, ciy, v[4]);
-                        v[5] = __builtin_fmaf(d_rgb, Q[q].gr, v[5]);             // RAST:650
-                        v[6] = __builtin_fmaf(d_rgb, Q[q].gg, v[6]);
-                        v[7] = __builtin_fmaf(d_rgb, Q[q].gb, v[7]);
-                        v[8] = __builtin_fmaf((ag * g) * (1.0f - apt), apt, v[8]);   // RAST:658-661
-                        v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
-                        v[10] += use ? 1.0f : 0.0f;                              // RAST:695-696
-                        if (use) {
+                        if (use) {                                               // exec-masked: idle lanes add nothing
+                            const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
+                            const float one_m = 1.0f - alpha;
+                            const float inv = __builtin_amdgcn_rcpf(one_m);
+                            float Tn = Q[q].T * inv;                              // RAST:643 (rcp + one correction)
+                            Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[q].T), inv, Tn);
+                            const float ag = (c4.x * Tn - Q[q].w0 * inv) * Q[q].gr + (c4.y * Tn - Q[q].w1 * inv) * Q[q].gg +
+                                             (c4.z * Tn - Q[q].w2 * inv) * Q[q].gb;   // RAST:653-657
+                            const float d_rgb = alpha * Tn;                     // RAST:649
+                            const float gag = ag * apt;                         // RAST:662
+                            const float hg = 0.5f * g * gag;
+                            const float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);   // RAST:664-665
+                            v[0] += vs0; v[1] += vs1;
+                            v[2] = __builtin_fmaf(hg * cix, cix, v[2]);
+                            v[3] = __builtin_fmaf(hg * cix, ciy, v[3]);
+                            v[4] = __builtin_fmaf(hg * ciy, ciy, v[4]);
+                            v[5] = __builtin_fmaf(d_rgb, Q[q].gr, v[5]);         // RAST:650
+                            v[6] = __builtin_fmaf(d_rgb, Q[q].gg, v[6]);
+                            v[7] = __builtin_fmaf(d_rgb, Q[q].gb, v[7]);
+                            v[8] = __builtin_fmaf((ag * g) * (1.0f - apt), apt, v[8]);   // RAST:658-661
+                            v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
+                            v[10] += 1.0f;                                       // RAST:695-696
                             Q[q].T = Tn;
-                            Q[q].w0 += c4.x * alpha * Tn; Q[q].w1 += c4.y * alpha * Tn; Q[q].w2 += c4.z * alpha * Tn;   // RAST:656
+                            const float wgt = alpha * Tn;
+                            Q[q].w0 = __builtin_fmaf(c4.x, wgt, Q[q].w0);        // RAST:656
+                            Q[q].w1 = __builtin_fmaf(c4.y, wgt, Q[q].w1);
+                            Q[q].w2 = __builtin_fmaf(c4.z, wgt, Q[q].w2);
+                            Q[q].tot0 += fabsf(vs0); Q[q].tot1 += fabsf(vs1);    // RAST:666-667
                         }
-                        Q[q].tot0 += fabsf(vs0); Q[q].tot1 += fabsf(vs1);        // RAST:666-667
                     }
                     if (!any_use) continue;
                     gs_wave_sum11_row3(v);

@@ -2,7 +2,7 @@
 # Print VGPR/SGPR/LDS/scratch/occupancy per kernel (hipcc -Rpass-analysis=kernel-resource-usage).
 cd "$(dirname "$0")"
 for f in k_blend_fwd k_backward k_project k_binning; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -c $f.hip -o /tmp/$f.res.o \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -c $f.hip -o /tmp/$f.res.o \
      -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None
