@@ -40,7 +40,8 @@ def kernel_models(N, M, K, P, T, key_bits):
         "k_tile_ranges": ("hbm", 4 * K + 8 * T),
         "k_blend_fwd": ("mfma", 16.0 * 256 * K),      # FP32 VALU flops; peak = 157.3 TF (= f32 MFMA peak)
         "k_blend_bwd_tile": ("mfma", 49.0 * 256 * K),
-        "k_bwd_points": ("hbm", 48 * K + 4 * N + 252 * M + 248 * N),   # 48 B/pair is the algorithmic row read; unvisited rows are skipped
+        "k_sum_rows": ("hbm", 49 * K + 8 * M + 48 * M),          # 48-B row + 1 flag byte per pair (unvisited rows are skipped in practice)
+        "k_bwd_points": ("hbm", 4 * N + 300 * M + 248 * N),
     }, passes
 
 

@@ -105,7 +105,7 @@ struct gs_ctx {
     std::vector<gs_frame*> frames;      // every handle ever issued (recycled)
     gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
-    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited;
+    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums;
     GsCounters* host_counters = nullptr;   // pinned
 };
 
@@ -115,7 +115,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* gs_kernel_names(void)
 {
     return "k_pose_prepare,k_filter,k_scan_blocks,k_store_M,k_compact,k_project,k_keygen,k_sort_hist,k_scan_reduce,"
-           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points";
+           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows";
 }
 
 extern "C" int gs_create(int32_t device, gs_ctx** out)
@@ -143,7 +143,7 @@ extern "C" int gs_destroy(gs_ctx* c)
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
     for (gs_frame* f : c->frames) delete f;
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
-                      &c->counters, &c->partial, &c->visited };
+                      &c->counters, &c->partial, &c->visited, &c->sums };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
@@ -403,8 +403,10 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     {
         hipError_t e = c->partial.ensure((size_t)(K > 0 ? K : 1) * 12 * sizeof(float), &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: partial-sum buffer");
-        e = c->visited.ensure((size_t)(K > 0 ? K : 1), &c->device_bytes);
+        e = c->visited.ensure(((size_t)K + 15) / 16 * 16 + 64, &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: visited buffer");
+        e = c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes);
+        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
     }
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
@@ -418,6 +420,9 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
+    a.visited_bytes = ((size_t)K + 15) / 16 * 16 + 48;
+    a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + ((size_t)K + 15) / 16 * 16);
+    a.sums = c->sums.as<float4>();
     a.point_cloud = sc->point_cloud; a.features = sc->point_cloud_features; a.object_id = sc->point_object_id;
     a.Kmat = cam->camera_intrinsics; a.pose = B.pose.as<GsPose>();
     a.sh_band = sh_band; a.f_color = cfg->grad_color_factor; a.f_high = cfg->grad_high_order_color_factor;

@@ -158,7 +158,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
 enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_SCAN_BLOCKS, KID_STORE_M, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
                   KID_SORT_HIST, KID_SCAN_REDUCE, KID_SCAN_APPLY, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
-                  KID_BLEND_BWD, KID_BWD_POINTS, KID_COUNT_ };
+                  KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
 void gs_prof_end(GsProf* p, int rec, hipStream_t s);
@@ -214,6 +214,9 @@ struct GsBackwardArgs {
     const float* grad_image; const float* acc_alpha; const int32_t* last;
     float* partial;                 // (K,12) per (point,tile) sums in slot order
     uint8_t* visited;               // (K) 1 where the row of `partial` was written this backward
+    size_t visited_bytes;           // K rounded up to 16 + 48: flags, then one all-zero 48-byte row
+    const float4* zero_row;         // that row
+    float4* sums;                   // (M,3) per-point sums of the visited rows
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
     float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;

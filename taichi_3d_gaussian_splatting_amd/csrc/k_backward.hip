@@ -204,9 +204,78 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------
+// Per-point sum of the visited rows of `partial` (fixed order => bitwise reproducible).  One lane
+// per in-camera point for points with at most 16 tiles (unconditional loads, four rows in flight;
+// unvisited rows read a shared all-zero row); a point with more tiles is summed by its whole wave
+// (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the
+// critical path of the launch.
+#define SUM_ROWS_SMALL 16
+__global__ __launch_bounds__(256) void k_sum_rows(int M, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
+                                                  const float* __restrict__ partial, const uint8_t* __restrict__ visited,
+                                                  const float4* __restrict__ zero_row, float4* __restrict__ sums)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = m < M;
+    const uint32_t off = valid ? offsets[m] : 0u;
+    const int cnt = valid ? ntiles[m] : 0;
+    if (valid && cnt <= SUM_ROWS_SMALL) {
+        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)off * PW);
+        const uint8_t* vis = visited + off;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+        for (int i = 0; i < cnt; i += 4) {
+            const float4* r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = (i + k < cnt) && vis[i + k] != 0;
+                r[k] = on ? rows + 3 * (i + k) : zero_row;
+            }
+            float4 a[4], b[4], c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = r[k][0]; b[k] = r[k][1]; c[k] = r[k][2]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s0.x += a[k].x; s0.y += a[k].y; s0.z += a[k].z; s0.w += a[k].w;
+                s1.x += b[k].x; s1.y += b[k].y; s1.z += b[k].z; s1.w += b[k].w;
+                s2.x += c[k].x; s2.y += c[k].y; s2.z += c[k].z; s2.w += c[k].w;
+            }
+        }
+        sums[3 * (size_t)m] = s0; sums[3 * (size_t)m + 1] = s1; sums[3 * (size_t)m + 2] = s2;
+    }
+    // wave-cooperative pass over the large points of this wave
+    unsigned long long big = __ballot(valid && cnt > SUM_ROWS_SMALL);
+    while (big) {
+        const int j = __builtin_ctzll(big);
+        big &= big - 1ull;
+        const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+        const int bcnt = __builtin_amdgcn_readlane(cnt, j);
+        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)boff * PW);
+        const uint8_t* vis = visited + boff;
+        float v[11];
+        float pad = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) v[k] = 0.0f;
+        for (int i = lane; i < bcnt; i += 64) {
+            if (vis[i]) {
+                const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                v[8] += c.x; v[9] += c.y; v[10] += c.z; pad += c.w;
+            }
+        }
+        gs_wave_sum11_row3(v);
+        if (lane == 63) {
+            const size_t mj = (size_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + j);
+            sums[3 * mj] = make_float4(v[0], v[1], v[2], v[3]);
+            sums[3 * mj + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            sums[3 * mj + 2] = make_float4(v[8], v[9], v[10], 0.0f);
+        }
+        (void)pad;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bwd_points(
-    int64_t N, const int32_t* __restrict__ cam_index, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
-    const float* __restrict__ partial, const uint8_t* __restrict__ visited, const float4* __restrict__ PD,
+    int64_t N, const int32_t* __restrict__ cam_index, const float4* __restrict__ sums, const float4* __restrict__ PD,
     const float* __restrict__ pc, const float* __restrict__ feat, const int32_t* __restrict__ obj,
     const float* __restrict__ Kmat, const GsPose* __restrict__ pose,
     int keep, float f_color, float f_high, float f_s, float f_q, float f_alpha,
@@ -226,22 +295,11 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         if (mag) mag[n] = 0.0f;
         return;
     }
-    // ---- sum this point's rows (slot order) ----
     float s[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) s[k] = 0.0f;
     {
-        const uint32_t off = offsets[m];
-        const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)off * PW);
-        const uint8_t* vis = visited + off;
-        const int cnt = ntiles[m];
-        for (int i = 0; i < cnt; ++i) {
-            if (!vis[i]) continue;                                  // pair never reached by any pixel: contributes nothing
-            float4 r0 = rows[3 * i], r1 = rows[3 * i + 1], r2 = rows[3 * i + 2];
-            s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
-            s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
-            s[8] += r2.x; s[9] += r2.y; s[10] += r2.z;
-        }
+        const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
+        s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
+        s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
     }
     const float guv0 = s[0], guv1 = s[1];
     const float g00 = s[2], g01 = s[3], g11 = s[4];
@@ -384,7 +442,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
-        (void)hipMemsetAsync(a.visited, 0, (size_t)a.K, s);
+        (void)hipMemsetAsync(a.visited, 0, a.visited_bytes, s);      // flags + the shared all-zero row behind them
         GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<<<a.T, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
                                                                            a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial,
                                                                            a.visited, a.mag_image));
@@ -394,7 +452,10 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
-    GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.offsets, a.ntiles, a.partial, a.visited, a.PD, a.point_cloud, a.features,
+    if (a.M > 0)
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(a.M + 255) / 256, 256, 0, s>>>(a.M, a.offsets, a.ntiles, a.partial, a.visited,
+                                                                                  a.zero_row, a.sums));
+    GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.sums, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
                                                                     a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
                                                                     a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag));
