@@ -14,6 +14,7 @@
 
 #define SORT_TILE 4096          // keys per tile: 256 threads x 16
 #define SORT_ROUNDS 16
+#define KEYGEN_SMALL 12        // a lane writes up to this many pairs itself; larger splats are written by the wave
 
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, const ushort4* __restrict__ boxes,
@@ -34,21 +35,50 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += ws[w];
-    if (idx >= M) return;
-    uint32_t off = tile_block_offsets[blockIdx.x] + woff + incl - n;
-    offsets[idx] = off;
-    ushort4 bx = boxes[idx];
-    int depth_code = (int)(PB[idx].w * depth_scale);                 // RAST:159-160
-    int dv = (int)bx.w - (int)bx.z;
-    for (int tu = bx.x; tu < bx.y; ++tu)
-        for (int tv = bx.z; tv < bx.w; ++tv) {
-            uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
+    const bool valid = idx < M;
+    const uint32_t off = tile_block_offsets[blockIdx.x] + woff + incl - n;
+    ushort4 bx = make_ushort4(0, 0, 0, 0);
+    KeyT depth_code = 0;
+    if (valid) {
+        offsets[idx] = off;
+        bx = boxes[idx];
+        depth_code = (KeyT)(uint32_t)(int)(PB[idx].w * depth_scale);         // RAST:159-160
+    }
+    const int du = (int)bx.y - (int)bx.x, dv = (int)bx.w - (int)bx.z;
+    // points with few tiles: one lane writes all of its pairs
+    if (valid && n <= KEYGEN_SMALL) {
+        for (int tu = bx.x; tu < bx.y; ++tu)
+            for (int tv = bx.z; tv < bx.w; ++tv) {
+                uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
+                if (slot < K_cap) {
+                    KeyT tile_id = (KeyT)(tu + tv * tiles_x);                       // RAST:167-168
+                    keys[slot] = (tile_id << depth_bits) | depth_code;
+                    vals[slot] = idx;
+                }
+            }
+    }
+    // points with many tiles: the wave writes them together, 64 consecutive slots per step
+    unsigned long long big = __ballot(valid && n > KEYGEN_SMALL);
+    while (big) {
+        const int j = __builtin_ctzll(big);
+        big &= big - 1ull;
+        const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+        const int bn = __builtin_amdgcn_readlane((int)n, j);
+        const int bu0 = __builtin_amdgcn_readlane((int)bx.x, j), bv0 = __builtin_amdgcn_readlane((int)bx.z, j);
+        const int bdv = __builtin_amdgcn_readlane(dv, j);
+        const uint32_t bcode = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)depth_code, j);
+        const int bidx = (int)(blockIdx.x * 256 + (threadIdx.x & ~63)) + j;
+        for (int t = lane; t < bn; t += 64) {
+            const int tu = bu0 + t / bdv, tv = bv0 + t % bdv;                       // slot order: tile_u outer, tile_v inner
+            const uint32_t slot = boff + (uint32_t)t;
             if (slot < K_cap) {
-                KeyT tile_id = (KeyT)(tu + tv * tiles_x);                       // RAST:167-168
-                keys[slot] = (tile_id << depth_bits) | (KeyT)(uint32_t)depth_code;
-                vals[slot] = idx;
+                KeyT tile_id = (KeyT)(tu + tv * tiles_x);
+                keys[slot] = (tile_id << depth_bits) | (KeyT)bcode;
+                vals[slot] = bidx;
             }
         }
+    }
+    (void)du;
 }
 
 template <typename KeyT>

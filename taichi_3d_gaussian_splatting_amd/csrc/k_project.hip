@@ -250,8 +250,6 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
     }
 }
 
-__global__ void k_store_M(const uint32_t* total, GsCounters* c) { c->M = (int32_t)*total; }
-
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
 {
     const int nb = (int)((a.N + 255) / 256);
@@ -261,8 +259,7 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
                                                             a.near_plane, a.far_plane, a.mask, a.block_counts));
     GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(reinterpret_cast<const uint32_t*>(a.block_counts),
                                                                       reinterpret_cast<uint32_t*>(a.block_offsets), nb,
-                                                                      reinterpret_cast<uint32_t*>(&a.counters->reserved)));
-    GS_TIMED(a.prof, KID_STORE_M, s, k_store_M<<<1, 1, 0, s>>>(reinterpret_cast<const uint32_t*>(&a.counters->reserved), a.counters));
+                                                                      reinterpret_cast<uint32_t*>(&a.counters->M)));
     GS_TIMED(a.prof, KID_COMPACT, s, k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_offsets, a.N, a.ids, a.cam_index));
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
