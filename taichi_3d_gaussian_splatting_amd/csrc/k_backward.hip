@@ -17,6 +17,7 @@
 #include "gs_common.h"
 #include <cstdlib>
 
+#define RED_STRIDE 68   // floats per value row of the LDS transpose (64 lanes + 4 pad: conflict-free b128 reads)
 #define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count | pad
 
 __device__ __forceinline__ float rect_min_quadratic_b(float a, float b, float c, float X0, float X1, float Y0, float Y1)
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                                                        float* __restrict__ partial, uint8_t* __restrict__ visited, float* __restrict__ mag_image)
 {
     __shared__ float4 sA[64], sB[64], sC[64];
+    __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
     const int tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
@@ -179,15 +181,26 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         }
                     }
                     if (!any_use) continue;
-                    gs_wave_sum11_row3(v);
-                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-                    if (lane == 63) {
-                        float4* dst = reinterpret_cast<float4*>(partial + (size_t)sj * PW);
-                        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-                        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-                        dst[2] = make_float4(v[8], v[9], v[10], 0.0f);
-                        visited[sj] = 1;
+                    // Sum the eleven values over the 64 lanes through a wave-private LDS transpose: 11 conflict-free
+                    // ds_write_b32, then lane 4k+s adds 16 floats of value k (4 ds_read_b128, row stride 68 floats
+                    // keeps the reads conflict-free) and two quad DPP adds fold s.  About 30 VALU issue slots
+                    // instead of 130+ for six half-rate DPP steps on eleven registers.
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) sRed[k * RED_STRIDE + lane] = v[k];
+                    __builtin_amdgcn_wave_barrier();
+                    float t = 0.0f;
+                    if (lane < 44) {
+                        const float4* src = reinterpret_cast<const float4*>(sRed + (lane >> 2) * RED_STRIDE + 16 * (lane & 3));
+                        const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+                        t = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+                            (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
                     }
+                    t += gs_dpp<0xB1>(t);              // quad_perm [1,0,3,2]
+                    t += gs_dpp<0x4E>(t);              // quad_perm [2,3,0,1]
+                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+                    if ((lane & 3) == 0 && lane < 48) partial[(size_t)sj * PW + (lane >> 2)] = t;   // 12 floats (pad = 0), one store
+                    if (lane == 63) visited[sj] = 1;
+                    __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_wave_barrier();
             }
