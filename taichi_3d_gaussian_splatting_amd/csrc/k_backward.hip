@@ -15,42 +15,11 @@
 //                 the BackwardValidPointHookInput gathers (RAST:1128-1140).
 // k_blend_bwd_tile is VALU/latency bound, k_bwd_points HBM bound: see DESIGN.md.
 #include "gs_common.h"
+#include "gs_cull.h"
 #include <cstdlib>
 
 #define RED_STRIDE 68   // floats per value row of the LDS transpose (64 lanes + 4 pad: conflict-free b128 reads)
 #define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count | pad
-
-__device__ __forceinline__ float rect_min_quadratic_b(float a, float b, float c, float X0, float X1, float Y0, float Y1)
-{
-    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float X = e ? X1 : X0;
-        float y = -(b * X) / c;
-        y = fminf(fmaxf(y, Y0), Y1);
-        best = fminf(best, a * X * X + 2.0f * b * X * y + c * y * y);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float Y = e ? Y1 : Y0;
-        float x = -(b * Y) / a;
-        x = fminf(fmaxf(x, X0), X1);
-        best = fminf(best, a * x * x + 2.0f * b * x * Y + c * Y * Y);
-    }
-    return best;
-}
-
-__device__ __forceinline__ bool gs_cull_b(float4 A, float4 B, float4 C, float rx0, float ry0)
-{
-    float a = A.z, b = A.w, c = B.x;
-    float X0 = rx0 - A.x, X1 = X0 + 7.0f, Y0 = ry0 - A.y, Y1 = Y0 + 7.0f;
-    float ax = fmaxf(fabsf(X0), fabsf(X1)), ay = fmaxf(fabsf(Y0), fabsf(Y1));
-    float slack = 0.02f + 4.0e-6f * (fabsf(a) * ax * ax + fabsf(c) * ay * ay + 2.0f * fabsf(b) * ax * ay);
-    bool pd = a > 0.0f && c > 0.0f && a * c > b * b;
-    float qmin = rect_min_quadratic_b(a, b, c, X0, X1, Y0, Y1);
-    return pd && (-0.5f * qmin + slack < C.w);
-}
 
 // ---------------------------------------------------------------------------------
 // Loop 1: ONE WAVE PER TILE, four pixels per lane (one per 8x8 quadrant).
@@ -108,10 +77,11 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
         const int p = valid ? sorted_vals[i] : 0;
         {
             const float4 A = PA[p], B = PB[p], C = PC[p];
+            const CullSplat cs = gs_cull_prepare(A, B, C);
             unsigned long long mq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                mq[q] = __ballot(valid && i < qlast[q] && !gs_cull_b(A, B, C, rx0[q], ry0[q]));
+                mq[q] = __ballot(valid && i < qlast[q] && !gs_cull(cs, rx0[q], ry0[q]));
             unsigned long long U = mq[0] | mq[1] | mq[2] | mq[3];
             if (U) {
                 uint32_t slot = 0;
@@ -138,19 +108,20 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         const float cix = a * dx + b * dy, ciy = b * dx + c * dy;
                         const float exponent = -0.5f * (dx * cix + dy * ciy);
                         const bool in_range = (lo + j) < Q[q].last;              // RAST:609-610
-                        if (!__any(in_range && !(exponent + 0.02f < c4.w))) continue;
+                        if (__ballot(in_range && !(exponent + 0.02f < c4.w)) == 0ull) continue;
                         // exp: the hardware v_exp_f32 (1 ulp) unless some lane sits within 1e-5 (relative) of the
                         // 1/255 threshold, where the reference polynomial decides (same decisions as the oracle)
                         float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
                         float prod_alpha = g * apt;
-                        if (__any(in_range && fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f)) {
+                        if (__ballot(in_range && fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) != 0ull) {
                             g = gs_expf(exponent) * b4.y;
                             prod_alpha = g * apt;
                         }
                         const bool use = in_range && prod_alpha >= GS_ALPHA_EPS; // RAST:634
-                        if (!__any(use)) continue;
-                        any_use = true;
+                        any_use = any_use || (__ballot(use) != 0ull);
                         if (use) {                                               // exec-masked: idle lanes add nothing
+                            // float outputs only from here on: let the compiler fuse multiply-adds
+#pragma clang fp contract(fast)
                             const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
                             const float one_m = 1.0f - alpha;
                             const float inv = __builtin_amdgcn_rcpf(one_m);

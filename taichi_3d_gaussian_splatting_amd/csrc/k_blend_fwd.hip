@@ -13,45 +13,7 @@
 // alpha < 1/255 test for every pixel of the quadrant (RAST:451-452).
 // Bound: FP32 VALU (exp polynomial + blend), not HBM: see DESIGN.md.
 #include "gs_common.h"
-
-// min over the rectangle [X0,X1]x[Y0,Y1] (pixel centre minus mean) of q = a x^2 + 2 b x y + c y^2
-__device__ __forceinline__ float rect_min_quadratic(float a, float b, float c, float X0, float X1, float Y0, float Y1)
-{
-    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
-    float best = 3.0e38f;
-    // edges x = X0, X1 : minimise over y
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float X = e ? X1 : X0;
-        float y = -(b * X) / c;
-        y = fminf(fmaxf(y, Y0), Y1);
-        float q = a * X * X + 2.0f * b * X * y + c * y * y;
-        best = fminf(best, q);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float Y = e ? Y1 : Y0;
-        float x = -(b * Y) / a;
-        x = fminf(fmaxf(x, X0), X1);
-        float q = a * x * x + 2.0f * b * x * Y + c * Y * Y;
-        best = fminf(best, q);
-    }
-    return best;
-}
-
-// true when the splat cannot reach alpha >= 1/255 anywhere in the rectangle.
-// Written so that any NaN makes the test false (= keep the splat).
-__device__ __forceinline__ bool gs_cull(float4 A, float4 B, float4 C, float rx0, float ry0)
-{
-    float a = A.z, b = A.w, c = B.x;
-    float X0 = rx0 - A.x, X1 = X0 + 7.0f, Y0 = ry0 - A.y, Y1 = Y0 + 7.0f;
-    float ax = fmaxf(fabsf(X0), fabsf(X1)), ay = fmaxf(fabsf(Y0), fabsf(Y1));
-    // rounding slack of the f32 exponent evaluated per pixel (terms can cancel for skewed conics)
-    float slack = 0.02f + 4.0e-6f * (fabsf(a) * ax * ax + fabsf(c) * ay * ay + 2.0f * fabsf(b) * ax * ay);
-    bool pd = a > 0.0f && c > 0.0f && a * c > b * b;
-    float qmin = rect_min_quadratic(a, b, c, X0, X1, Y0, Y1);
-    return pd && (-0.5f * qmin + slack < C.w);
-}
+#include "gs_cull.h"
 
 template <bool RGB_ONLY>
 __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
@@ -77,12 +39,12 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
     bool saturated = false;
 
     for (int base = start; base < end; base += 64) {
-        if (__all(saturated)) break;
+        if (__ballot(!saturated) == 0ull) break;
         const int i = base + lane;
         const bool valid = i < end;
         const int p = valid ? sorted_vals[i] : 0;
         float4 A = PA[p], B = PB[p], C = PC[p];
-        bool keep = valid && !gs_cull(A, B, C, rx0, ry0);
+        bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), rx0, ry0);
         unsigned long long mask = __ballot(keep);
         if (mask == 0ull) continue;
         sA[wave][lane] = A; sB[wave][lane] = B; sC[wave][lane] = C;
@@ -95,7 +57,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
             float dx = px - a4.x, dy = py - a4.y;
             float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
             // cheap wave-level reject before the polynomial: exp(e)*rescale*opacity < 1/255 for sure
-            if (!__any(!saturated && !(exponent + 0.02f < c4.w))) continue;
+            if (__ballot(!saturated && !(exponent + 0.02f < c4.w)) == 0ull) continue;
             float g = gs_expf(exponent) * b4.y;
             float alpha = g * b4.z;
             bool use = !saturated && !(alpha < GS_ALPHA_EPS);                    // RAST:451
@@ -111,7 +73,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
                 if (!RGB_ONLY) { acc_d += b4.w * alpha * T_i; norm += alpha * T_i; count += 1; } // RAST:464-469
                 T_i = next_T;
             }
-            if (__all(saturated)) { mask = 0ull; }
+            if (__ballot(!saturated) == 0ull) { mask = 0ull; }
         }
         __builtin_amdgcn_wave_barrier();
     }
