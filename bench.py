@@ -27,8 +27,10 @@ sys.path.insert(0, ROOT)
 KERNEL_MODEL_DOC = "DESIGN.md section 'Kernels and rooflines'"
 
 
-def kernel_models(N, M, K, P, T, key_bits):
-    """Algorithmic bytes / flops ONE launch of each kernel has to move.  bound, amount."""
+def kernel_models(N, M, K, P, T, key_bits, evals):
+    """Algorithmic bytes / flops ONE launch of each kernel has to move.  bound, amount.
+    `evals` = pixel x list-entry evaluations the reference algorithm performs on this frame
+    (sum over pixels of last_effective_index - tile_start; a saturated pixel stops there, RAST:424-425, 609-610)."""
     passes = (key_bits + 7) // 8
     return {
         "k_filter": ("hbm", 17 * N + 1 * N),
@@ -38,8 +40,8 @@ def kernel_models(N, M, K, P, T, key_bits):
         "k_sort_hist": ("hbm", 4 * K),
         "k_sort_scatter": ("hbm", 16 * K),
         "k_tile_ranges": ("hbm", 4 * K + 8 * T),
-        "k_blend_fwd": ("mfma", 16.0 * 256 * K),      # FP32 VALU flops; peak = 157.3 TF (= f32 MFMA peak)
-        "k_blend_bwd_tile": ("mfma", 49.0 * 256 * K),
+        "k_blend_fwd": ("mfma", 16.3 * evals),        # FP32 VALU flops; peak = 157.3 TF (= f32 MFMA peak)
+        "k_blend_bwd_tile": ("mfma", 48.8 * evals),
         "k_sum_rows": ("hbm", 49 * K + 8 * M + 48 * M),          # 48-B row + 1 flag byte per pair (unvisited rows are skipped in practice)
         "k_bwd_points": ("hbm", 4 * N + 300 * M + 248 * N),
     }, passes
@@ -65,9 +67,14 @@ def main():
     from taichi_3d_gaussian_splatting_amd import distributed as gsd
     from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose
 
-    rank, world, local_rank = gsd.init_from_env("nccl")
+    # GS_BENCH_REHEARSAL=1: every rank uses cuda:0 and the collective runs over gloo -- only to rehearse the
+    # N > 1 code path on a one-GPU box; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("GS_BENCH_REHEARSAL") == "1"
+    rank, world, local_rank = gsd.init_from_env("gloo" if rehearsal else "nccl")
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -88,6 +95,8 @@ def main():
     L = _native.lib()
     names = L.gs_kernel_names().decode().split(",")
 
+    ncoll = []
+
     def step():
         pc.grad = None
         feat.grad = None
@@ -95,7 +104,7 @@ def main():
         g = 2.0 * (image.detach() - 0.5)                 # dL/dimage of an MSE to mid-grey
         image.backward(g)
         if world > 1:
-            gsd.all_reduce_point_gradients(pc.grad, feat.grad)
+            ncoll.append(gsd.all_reduce_point_gradients(pc.grad, feat.grad))
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -119,9 +128,16 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     sync_all()
+    with torch.no_grad():                      # an inference call leaves a frame that can still be inspected
+        module(inp)
     fr = module.last_frame
     M, K, T, key_bits = fr.n_points_in_camera, fr.n_keys, fr.n_tiles, fr.sort_key_bits
     N, P = pc.shape[0], H * W
+    # evaluations the reference algorithm performs: every pixel walks its tile list up to its last effective entry
+    last = module.last_forward_outputs["pixel_offset_of_last_effective_point"].to(torch.int64)
+    tstart = fr.export("tile_points_start").to(torch.int64).view(H // 16, 1, W // 16, 1)
+    evals = int((last.view(H // 16, 16, W // 16, 16) - tstart).clamp_(min=0).sum().item())
+    sync_all()
 
     # ---- untimed diagnostic pass: every kernel timed, to find the dominant one ----
     prof((1 << len(names)) - 1)
@@ -148,7 +164,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        models, passes = kernel_models(N, M, K, P, T, key_bits)
+        models, passes = kernel_models(N, M, K, P, T, key_bits, evals)
         bound, amount = models.get(dominant, ("hbm", 0))
         avg_ms = dom[0] / max(dom[1], 1)
         peak, unit = PEAK[bound]
@@ -172,7 +188,9 @@ def main():
             "config": {"workload": f"{args.workload}: synth(N={cfgw['N']}, {W}x{H}, sigma0={cfgw['sigma0']}, sh_deg={cfgw['sh_deg']}, seed 0), "
                                    f"fwd+bwd, one view per GPU, sum all-reduce of 59*N f32 point gradients when N>1",
                        "points": N, "points_in_camera": M, "sort_pairs": K, "tiles": T, "sort_key_bits": key_bits,
-                       "parallelism": f"view-parallel x{world}"},
+                       "pixel_entry_evaluations": evals,
+                       "parallelism": f"view-parallel x{world}",
+                       "collectives_per_step": (ncoll[-1] if ncoll else 0), "rehearsal": rehearsal},
             "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": dom[1], "model": KERNEL_MODEL_DOC},

@@ -136,6 +136,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self._hook = backward_valid_point_hook
         self._ctxs = {}                     # device index -> gs_ctx*
         self.last_frame: Optional[_Frame] = None   # inspection aid (tests / profiling); replaced every call
+        self.last_forward_outputs = {}
         module = self
 
         class _module_function(torch.autograd.Function):
@@ -236,6 +237,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         if not keep:
             frame.release = lambda: None     # transient frames belong to the ctx; nothing to release
         self.last_frame = frame
+        self.last_forward_outputs = {"pixel_accumulated_alpha": acc_alpha, "pixel_offset_of_last_effective_point": last}
         return (image, depth, acc_alpha, last, count), frame
 
     def _run_backward(self, frame, pointcloud, features, mask, obj, q, t, camera_info, acc_alpha, last, grad_image, sh_band):
