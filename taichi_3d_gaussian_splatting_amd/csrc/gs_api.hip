@@ -62,7 +62,8 @@ struct gs_frame {
     FrameBufs* bufs = nullptr;
     gs_frame_info info{};
     int depth_bits = 0;
-    uint32_t* keys_sorted = nullptr;
+    void* keys_sorted = nullptr;
+    int key64 = 0;
     int32_t* vals_sorted = nullptr;
     bool live = false;
 };
@@ -290,13 +291,11 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
     const int depth_bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
     const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
-    if (depth_bits + tile_bits > 32) {
-        drop_frame(c, f);
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: depth code needs " + std::to_string(depth_bits) + " bits and tile id " +
-                    std::to_string(tile_bits) + "; compact 32-bit sort keys exhausted (lower depth_to_sort_key_scale)");
-    }
+    const int key64 = depth_bits + tile_bits > 32 ? 1 : 0;      // compact 32-bit keys whenever they fit
+    if (depth_bits + tile_bits > 63) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: sort key needs more than 63 bits"); }
     const size_t Kp = K > 0 ? K : 1;
-    ENSURE(B.keys_a, 4 * Kp); ENSURE(B.keys_b, 4 * Kp); ENSURE(B.vals_a, 4 * Kp); ENSURE(B.vals_b, 4 * Kp);
+    const size_t key_bytes = key64 ? 8 : 4;
+    ENSURE(B.keys_a, key_bytes * Kp); ENSURE(B.keys_b, key_bytes * Kp); ENSURE(B.vals_a, 4 * Kp); ENSURE(B.vals_b, 4 * Kp);
     const size_t hist_elems = gs_sort_hist_elems(K);
     ENSURE(c->hist, 4 * hist_elems); ENSURE(c->scan_tmp, 4 * gs_scan_tmp_elems(hist_elems));
 
@@ -306,7 +305,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
     ba.offsets = B.offsets.as<uint32_t>();
-    ba.keys_a = B.keys_a.as<uint32_t>(); ba.keys_b = B.keys_b.as<uint32_t>();
+    ba.keys_a = B.keys_a.p; ba.keys_b = B.keys_b.p; ba.key64 = key64;
     ba.vals_a = B.vals_a.as<int32_t>(); ba.vals_b = B.vals_b.as<int32_t>();
     ba.hist = c->hist.as<uint32_t>(); ba.scan_tmp = c->scan_tmp.as<uint32_t>();
     ba.tile_start = B.tile_start.as<int32_t>(); ba.tile_end = B.tile_end.as<int32_t>(); ba.T = T;
@@ -326,6 +325,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     HIP_TRY_F(hipGetLastError());
 
     f->depth_bits = depth_bits;
+    f->key64 = key64;
     f->info.n_points = N; f->info.n_points_in_camera = M; f->info.n_keys = K; f->info.n_tiles = T;
     f->info.camera_height = H; f->info.camera_width = W; f->info.sort_key_bits = depth_bits + tile_bits;
     f->info.kept_for_backward = keep ? 1 : 0;
@@ -369,7 +369,7 @@ extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_
     const FrameBufs& B = *f->bufs;
     GsExportArgs a{};
     a.what = (int)what; a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = (uint32_t)f->info.n_keys;
-    a.T = f->info.n_tiles; a.depth_bits = f->depth_bits;
+    a.T = f->info.n_tiles; a.depth_bits = f->depth_bits; a.key64 = f->key64;
     a.ids = B.ids.as<int32_t>(); a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
     a.ntiles = B.ntiles.as<int32_t>(); a.offsets = B.offsets.as<uint32_t>();
     a.keys_sorted = f->keys_sorted; a.vals_sorted = f->vals_sorted;

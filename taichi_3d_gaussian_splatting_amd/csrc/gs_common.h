@@ -186,11 +186,12 @@ struct GsBinArgs {
     int64_t N; int M; uint32_t K; int H, W; float depth_scale; int depth_bits; int key_bits;
     const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
-    uint32_t *keys_a, *keys_b; int32_t *vals_a, *vals_b;   // ping-pong (K)
+    void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64
+    int key64;                                             // depth bits + tile bits > 32
     uint32_t* hist;                             // (256 * sort_blocks) + scratch
     uint32_t* scan_tmp;                         // scratch for the scan
     int32_t *tile_start, *tile_end; int T;
-    uint32_t** keys_sorted; int32_t** vals_sorted;   // out: which of a/b holds the result
+    void** keys_sorted; int32_t** vals_sorted;       // out: which of a/b holds the result
 };
 void gs_launch_binning(const GsBinArgs& a, hipStream_t s);
 size_t gs_sort_hist_elems(uint32_t K);
@@ -224,7 +225,7 @@ struct GsBackwardArgs {
 };
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s);
 
-struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_bits;
+struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_bits; int key64;
     const int32_t* ids; const float4 *PA, *PB, *PC, *PD; const int32_t* ntiles; const uint32_t* offsets;
-    const uint32_t* keys_sorted; const int32_t* vals_sorted; const int32_t *tile_start, *tile_end; const int8_t* mask; void* dst; };
+    const void* keys_sorted; const int32_t* vals_sorted; const int32_t *tile_start, *tile_end; const int8_t* mask; void* dst; };
 void gs_launch_export(const GsExportArgs& a, hipStream_t s);

@@ -197,29 +197,37 @@ size_t gs_sort_hist_elems(uint32_t K)
 
 size_t gs_scan_tmp_elems(size_t n) { return 2 * ((n + GS_SCAN_CHUNK - 1) / GS_SCAN_CHUNK) + 16; }
 
-void gs_launch_binning(const GsBinArgs& a, hipStream_t s)
+template <typename KeyT>
+static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
 {
-    (void)hipMemsetAsync(a.tile_start, 0, sizeof(int32_t) * a.T, s);     // RAST:954-957
-    (void)hipMemsetAsync(a.tile_end, 0, sizeof(int32_t) * a.T, s);
+    KeyT* keys_a = reinterpret_cast<KeyT*>(a.keys_a);
+    KeyT* keys_b = reinterpret_cast<KeyT*>(a.keys_b);
     *a.keys_sorted = a.keys_a;
     *a.vals_sorted = a.vals_a;
-    const int nbM = (int)((a.N + 255) / 256);
-    if (nbM == 0 || a.M == 0) return;
-    GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<uint32_t><<<(a.M + 255) / 256, 256, 0, s>>>(
-        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.W / GS_TILE_SZ, a.depth_scale, a.depth_bits, a.K, a.offsets, a.keys_a, a.vals_a));
+    if (a.N == 0 || a.M == 0) return;
+    GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<(a.M + 255) / 256, 256, 0, s>>>(
+        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.W / GS_TILE_SZ, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
     if (a.K == 0) return;
     int nb, tpb;
     sort_geometry(a.K, &nb, &tpb);
-    uint32_t *kin = a.keys_a, *kout = a.keys_b;
+    KeyT *kin = keys_a, *kout = keys_b;
     int32_t *vin = a.vals_a, *vout = a.vals_b;
     for (int shift = 0; shift < a.key_bits; shift += 8) {
-        GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<uint32_t><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
+        GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
         gs_scan_u32(a.hist, a.hist, 256 * nb, a.scan_tmp, nullptr, s, a.prof);
-        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<uint32_t><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, a.hist, nb, tpb));
-        uint32_t* tk = kin; kin = kout; kout = tk;
+        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, a.hist, nb, tpb));
+        KeyT* tk = kin; kin = kout; kout = tk;
         int32_t* tv = vin; vin = vout; vout = tv;
     }
     *a.keys_sorted = kin;
     *a.vals_sorted = vin;
-    GS_TIMED(a.prof, KID_TILE_RANGES, s, k_tile_ranges<uint32_t><<<(a.K + 255) / 256, 256, 0, s>>>(kin, a.K, a.depth_bits, a.tile_start, a.tile_end));
+    GS_TIMED(a.prof, KID_TILE_RANGES, s, k_tile_ranges<KeyT><<<(a.K + 255) / 256, 256, 0, s>>>(kin, a.K, a.depth_bits, a.tile_start, a.tile_end));
+}
+
+void gs_launch_binning(const GsBinArgs& a, hipStream_t s)
+{
+    (void)hipMemsetAsync(a.tile_start, 0, sizeof(int32_t) * a.T, s);     // RAST:954-957
+    (void)hipMemsetAsync(a.tile_end, 0, sizeof(int32_t) * a.T, s);
+    if (a.key64) launch_binning_t<uint64_t>(a, s);
+    else launch_binning_t<uint32_t>(a, s);
 }

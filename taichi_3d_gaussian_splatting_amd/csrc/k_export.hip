@@ -19,9 +19,9 @@ __global__ void k_export(GsExportArgs a)
     case GS_X_ACCUMULATED_NUM_OVERLAP_TILES: if (i < a.M) ((int64_t*)a.dst)[i] = (int64_t)a.offsets[i]; break;
     case GS_X_SORT_KEY:
         if (i < (int64_t)a.K) {
-            uint32_t k = a.keys_sorted[i];
+            uint64_t k = a.key64 ? ((const uint64_t*)a.keys_sorted)[i] : (uint64_t)((const uint32_t*)a.keys_sorted)[i];
             int64_t tile = (int64_t)(k >> a.depth_bits);
-            int64_t code = (int64_t)(k & ((1u << a.depth_bits) - 1u));
+            int64_t code = (int64_t)(k & ((1ull << a.depth_bits) - 1ull));
             ((int64_t*)a.dst)[i] = code + (tile << 32);                    // RAST:169-170
         }
         break;

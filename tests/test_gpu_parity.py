@@ -181,3 +181,58 @@ def test_cfg2_truck7k_scale_parity(P):
     s = synth(**CONFIGS["cfg2_truck7k"])
     q, t = view_pose()
     _fwd_bwd(P, s, q, t, band=3, hook=True)
+
+
+def test_sort_keys_wider_than_32_bits(P):
+    """A depth code of 31 bits + tile bits forces the 64-bit key path; same order as the oracle's i64 sort."""
+    s = synth(3000, 160, 96, 0.08, sh_deg=3, seed=4)
+    q, t = view_pose()
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t, cfg_kw=dict(depth_to_sort_key_scale=2.0e8), hook=False)
+    assert module.last_backward_extras is not None
+    with torch.no_grad():
+        module(P.make_input(s, q, t, requires_grad=False))
+    assert module.last_frame.sort_key_bits > 32
+    assert int(f.sort_key.max() & 0xFFFFFFFF) > 2 ** 30
+
+
+def test_cfg3_headline_full_parity(P):
+    """BASELINE config 3 at full size: 5e5 Gaussians, 1920x1088, SH degree 3, forward + backward."""
+    s = synth(**CONFIGS["cfg3_headline"])
+    q, t = view_pose()
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True)
+    assert f.M == 472215 and f.K == 5999394
+
+
+def test_cfg3_views_of_the_8_gpu_run(P):
+    """Two of the eight poses of BASELINE config 4 (the views ranks 0 and 7 render)."""
+    s = synth(**CONFIGS["cfg3_headline"])
+    for v in (0, 7):
+        q, t = view_pose(v, 8)
+        _fwd_bwd(P, s, q, t, band=3, hook=False, seed=v)
+
+
+def test_cfg5_inference_2e6_forward_parity_and_properties(P):
+    """BASELINE config 5: 2e6 Gaussians, 1920x1088, inference (no_grad), all outputs."""
+    s = synth(**CONFIGS["cfg5_infer2e6"])
+    q, t = view_pose()
+    f, feat_after = P.run_oracle(s, q, t)
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t, requires_grad=False)
+    with torch.no_grad():
+        outs = module(inp)
+    P.assert_forward_parity(module, inp, outs, f, feat_after)
+    # size-independent properties of the binning, checked on the GPU result itself
+    fr = module.last_frame
+    keys = fr.export("sort_key")
+    vals = fr.export("point_offset_with_sort_key").to(torch.int64)
+    assert bool((keys[1:] >= keys[:-1]).all()), "keys sorted"
+    ties = keys[1:] == keys[:-1]
+    assert bool((vals[1:][ties] > vals[:-1][ties]).all()), "stable: ties keep ascending in-camera offset"
+    ts, te = fr.export("tile_points_start").to(torch.int64), fr.export("tile_points_end").to(torch.int64)
+    assert int((te - ts).sum()) == fr.n_keys == int(fr.export("num_overlap_tiles").sum())
+    tile_of_key = keys >> 32
+    nonempty = te > ts
+    assert bool((tile_of_key[ts[nonempty]] == torch.nonzero(nonempty).flatten()).all())
+    assert bool((tile_of_key[te[nonempty] - 1] == torch.nonzero(nonempty).flatten()).all())
+    image, depth, count = outs
+    assert float(image.min()) >= 0.0 and float(image.max()) <= 1.0 + 1e-5
