@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg3_headline")
+    ap.add_argument("--mode", choices=["fwdbwd", "forward"], default=None,
+                    help="forward = inference under torch.no_grad (BASELINE config 5); default: forward for cfg5, fwd+bwd otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--breakdown-steps", type=int, default=10)
@@ -78,6 +80,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    mode = args.mode or ("forward" if args.workload.startswith("cfg5") else "fwdbwd")
     cfgw = CONFIGS[args.workload]
     scene = synth(**cfgw)
     q, t = view_pose(rank, world)
@@ -98,6 +101,10 @@ def main():
     ncoll = []
 
     def step():
+        if mode == "forward":
+            with torch.no_grad():
+                module(inp)
+            return
         pc.grad = None
         feat.grad = None
         image, _, _ = module(inp)
@@ -177,16 +184,17 @@ def main():
             except Exception:
                 traffic = None
         fwd_bytes = 17 * N + 332 * M + 88 * K + 28 * P + 8 * T          # SURVEY 8d byte model
-        bwd_bytes = 88 * K + 28 * P + 528 * M + 248 * N
+        bwd_bytes = (88 * K + 28 * P + 528 * M + 248 * N) if mode == "fwdbwd" else 0
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "fps fwd+bwd @1920x1080 (run as 1920x1088), 5e5 Gaussians",
+            "metric": ("fps fwd+bwd @1920x1080 (run as 1920x1088), 5e5 Gaussians" if args.workload == "cfg3_headline" and mode == "fwdbwd"
+                       else f"fps {mode} {args.workload} @{W}x{H}, {N} Gaussians"),
             "value": round(world * args.steps / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: synth(N={cfgw['N']}, {W}x{H}, sigma0={cfgw['sigma0']}, sh_deg={cfgw['sh_deg']}, seed 0), "
-                                   f"fwd+bwd, one view per GPU, sum all-reduce of 59*N f32 point gradients when N>1",
+                                   f"{'fwd+bwd' if mode == 'fwdbwd' else 'forward only (torch.no_grad)'}, one view per GPU, sum all-reduce of 59*N f32 point gradients when N>1",
                        "points": N, "points_in_camera": M, "sort_pairs": K, "tiles": T, "sort_key_bits": key_bits,
                        "pixel_entry_evaluations": evals,
                        "parallelism": f"view-parallel x{world}",
@@ -206,13 +214,14 @@ def main():
                 c0 = time.perf_counter()
                 f, _ = oracle.forward(scene.point_cloud, scene.point_cloud_features, scene.point_invalid_mask,
                                       scene.point_object_id, q, t, scene.camera_intrinsics, H, W)
-                oracle.backward(f, 2.0 * (f.rasterized_image - 0.5), 3)
+                if mode == "fwdbwd":
+                    oracle.backward(f, 2.0 * (f.rasterized_image - 0.5), 3)
                 reps.append(time.perf_counter() - c0)
                 f.free()
             best = float(np.median(reps[1:]))
             out["cpu_baseline"] = {"value": round(1.0 / best, 4), "unit": "frames/s", "cores": oracle.num_threads(),
                                    "kind": "port",
-                                   "sample": f"the whole {args.workload} frame, fwd+bwd, median of {args.cpu_reps} runs after 1 warm-up "
+                                   "sample": f"the whole {args.workload} frame, {mode}, median of {args.cpu_reps} runs after 1 warm-up "
                                              f"({best:.2f} s/frame); oracle/gs_oracle.c -O2 -fopenmp, host has {os.cpu_count()} logical CPUs"}
         print(json.dumps(out), flush=True)
     if world > 1:

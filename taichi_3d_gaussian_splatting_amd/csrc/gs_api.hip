@@ -9,6 +9,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 static thread_local std::string g_last_error;
 
@@ -400,10 +401,19 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t K = (uint32_t)f->info.n_keys;
+    // waves per tile of the backward blend: one wave per tile is the cheapest in instructions, but a small image
+    // has too few tiles to fill 1024 SIMDs, so tiles are split into 2 or 4 quadrant groups (more rows of `partial`)
+    int G = 1;
+    if (const char* e = getenv("GS_BWD_WAVES_PER_TILE")) G = atoi(e);
+    else if (f->info.n_tiles < 3072) G = 4;
+    else if (f->info.n_tiles < 6144) G = 2;
+    if (G != 1 && G != 2 && G != 4) G = 1;
+    const size_t rows = (size_t)(K > 0 ? K : 1) * (size_t)G;
+    const size_t flag_bytes = (rows + 15) / 16 * 16;
     {
-        hipError_t e = c->partial.ensure((size_t)(K > 0 ? K : 1) * 12 * sizeof(float), &c->device_bytes);
+        hipError_t e = c->partial.ensure(rows * 12 * sizeof(float), &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: partial-sum buffer");
-        e = c->visited.ensure(((size_t)K + 15) / 16 * 16 + 64, &c->device_bytes);
+        e = c->visited.ensure(flag_bytes + 64, &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: visited buffer");
         e = c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes);
         if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
@@ -420,8 +430,9 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
-    a.visited_bytes = ((size_t)K + 15) / 16 * 16 + 48;
-    a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + ((size_t)K + 15) / 16 * 16);
+    a.G = G;
+    a.visited_bytes = flag_bytes + 48;
+    a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + flag_bytes);
     a.sums = c->sums.as<float4>();
     a.point_cloud = sc->point_cloud; a.features = sc->point_cloud_features; a.object_id = sc->point_object_id;
     a.Kmat = cam->camera_intrinsics; a.pose = B.pose.as<GsPose>();

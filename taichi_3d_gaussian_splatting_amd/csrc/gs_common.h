@@ -213,8 +213,9 @@ struct GsBackwardArgs {
     const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;
-    float* partial;                 // (K,12) per (point,tile) sums in slot order
-    uint8_t* visited;               // (K) 1 where the row of `partial` was written this backward
+    int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
+    float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
+    uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward
     size_t visited_bytes;           // K rounded up to 16 + 48: flags, then one all-zero 48-byte row
     const float4* zero_row;         // that row
     float4* sums;                   // (M,3) per-point sums of the visited rows

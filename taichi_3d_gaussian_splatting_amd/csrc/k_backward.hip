@@ -34,6 +34,9 @@
 // written and their `visited` byte stays 0 (the array is cleared by a memset per backward).
 struct QuadState { float T, w0, w1, w2, gr, gg, gb, tot0, tot1; int last; };
 
+// NQ = quadrants per wave: 4 (one wave per tile), 2 (two waves per tile, upper / lower half) or 1.
+// With G = 4/NQ waves per tile every (point, tile) pair owns G consecutive rows of `partial`.
+template <int NQ>
 __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                        const int32_t* __restrict__ sorted_vals,
                                                        const float4* __restrict__ PA, const float4* __restrict__ PB,
@@ -45,28 +48,33 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 {
     __shared__ float4 sA[64], sB[64], sC[64];
     __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
-    const int tile = blockIdx.x;
+    constexpr int G = 4 / NQ;
+    const int tile = blockIdx.x / G;
+    const int grp = blockIdx.x % G;               // which NQ quadrants of the tile this wave owns
     const int lane = threadIdx.x;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
     const int start = tile_start[tile], end = tile_end[tile];
     const int lx = lane & 7, ly = lane >> 3;
-    QuadState Q[4];
-    int qlast[4];
-    float rx0[4], ry0[4];
+    QuadState Q[NQ];
+    int qlast[NQ];
+    float rx0[NQ], ry0[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int qi = 0; qi < NQ; ++qi) {
+        const int q = grp * NQ + qi;
         const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
         const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
-        Q[q].last = last_in[o];                                     // RAST:558
-        Q[q].T = 1.0f - acc_alpha[o];                               // RAST:559-560
-        Q[q].w0 = Q[q].w1 = Q[q].w2 = 0.0f;
-        Q[q].gr = grad_image[3 * o]; Q[q].gg = grad_image[3 * o + 1]; Q[q].gb = grad_image[3 * o + 2];
-        Q[q].tot0 = Q[q].tot1 = 0.0f;
-        qlast[q] = gs_wave_max_i(Q[q].last);
-        rx0[q] = (float)(tile_u * 16 + (q & 1) * 8) + 0.5f;
-        ry0[q] = (float)(tile_v * 16 + (q >> 1) * 8) + 0.5f;
+        Q[qi].last = last_in[o];                                     // RAST:558
+        Q[qi].T = 1.0f - acc_alpha[o];                               // RAST:559-560
+        Q[qi].w0 = Q[qi].w1 = Q[qi].w2 = 0.0f;
+        Q[qi].gr = grad_image[3 * o]; Q[qi].gg = grad_image[3 * o + 1]; Q[qi].gb = grad_image[3 * o + 2];
+        Q[qi].tot0 = Q[qi].tot1 = 0.0f;
+        qlast[qi] = gs_wave_max_i(Q[qi].last);
+        rx0[qi] = (float)(tile_u * 16 + (q & 1) * 8) + 0.5f;
+        ry0[qi] = (float)(tile_v * 16 + (q >> 1) * 8) + 0.5f;
     }
-    const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
+    int tile_last = qlast[0];
+#pragma unroll
+    for (int qi = 1; qi < NQ; ++qi) tile_last = max(tile_last, qlast[qi]);
     const float px_lo = (float)(tile_u * 16 + lx) + 0.5f, py_lo = (float)(tile_v * 16 + ly) + 0.5f;
 
     // entries at or beyond tile_last are dead for every pixel of the tile (RAST:609-610)
@@ -78,16 +86,18 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
         {
             const float4 A = PA[p], B = PB[p], C = PC[p];
             const CullSplat cs = gs_cull_prepare(A, B, C);
-            unsigned long long mq[4];
+            unsigned long long mq[NQ];
+            unsigned long long U = 0ull;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                mq[q] = __ballot(valid && i < qlast[q] && !gs_cull(cs, rx0[q], ry0[q]));
-            unsigned long long U = mq[0] | mq[1] | mq[2] | mq[3];
+            for (int qi = 0; qi < NQ; ++qi) {
+                mq[qi] = __ballot(valid && i < qlast[qi] && !gs_cull(cs, rx0[qi], ry0[qi]));
+                U |= mq[qi];
+            }
             if (U) {
                 uint32_t slot = 0;
                 if ((U >> lane) & 1ull) {                                     // pre-sort slot of this (point, tile) pair
                     const ushort4 bx = boxes[p];
-                    slot = offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z));
+                    slot = (offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z))) * G + grp;
                 }
                 sA[lane] = A; sB[lane] = B; sC[lane] = C;
                 __builtin_amdgcn_wave_barrier();
@@ -101,13 +111,14 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     for (int k = 0; k < 11; ++k) v[k] = 0.0f;
                     bool any_use = false;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (!((mq[q] >> j) & 1ull)) continue;                 // wave-uniform
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        if (!((mq[qi] >> j) & 1ull)) continue;                // wave-uniform
+                        const int q = grp * NQ + qi;
                         // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
                         const float dx = (px_lo + (float)((q & 1) * 8)) - a4.x, dy = (py_lo + (float)((q >> 1) * 8)) - a4.y;
                         const float cix = a * dx + b * dy, ciy = b * dx + c * dy;
                         const float exponent = -0.5f * (dx * cix + dy * ciy);
-                        const bool in_range = (lo + j) < Q[q].last;              // RAST:609-610
+                        const bool in_range = (lo + j) < Q[qi].last;              // RAST:609-610
                         if (__ballot(in_range && !(exponent + 0.02f < c4.w)) == 0ull) continue;
                         // exp: the hardware v_exp_f32 (1 ulp) unless some lane sits within 1e-5 (relative) of the
                         // 1/255 threshold, where the reference polynomial decides (same decisions as the oracle)
@@ -125,10 +136,10 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
                             const float one_m = 1.0f - alpha;
                             const float inv = __builtin_amdgcn_rcpf(one_m);
-                            float Tn = Q[q].T * inv;                              // RAST:643 (rcp + one correction)
-                            Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[q].T), inv, Tn);
-                            const float ag = (c4.x * Tn - Q[q].w0 * inv) * Q[q].gr + (c4.y * Tn - Q[q].w1 * inv) * Q[q].gg +
-                                             (c4.z * Tn - Q[q].w2 * inv) * Q[q].gb;   // RAST:653-657
+                            float Tn = Q[qi].T * inv;                              // RAST:643 (rcp + one correction)
+                            Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[qi].T), inv, Tn);
+                            const float ag = (c4.x * Tn - Q[qi].w0 * inv) * Q[qi].gr + (c4.y * Tn - Q[qi].w1 * inv) * Q[qi].gg +
+                                             (c4.z * Tn - Q[qi].w2 * inv) * Q[qi].gb;   // RAST:653-657
                             const float d_rgb = alpha * Tn;                     // RAST:649
                             const float gag = ag * apt;                         // RAST:662
                             const float hg = 0.5f * g * gag;
@@ -137,18 +148,18 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             v[2] = __builtin_fmaf(hg * cix, cix, v[2]);
                             v[3] = __builtin_fmaf(hg * cix, ciy, v[3]);
                             v[4] = __builtin_fmaf(hg * ciy, ciy, v[4]);
-                            v[5] = __builtin_fmaf(d_rgb, Q[q].gr, v[5]);         // RAST:650
-                            v[6] = __builtin_fmaf(d_rgb, Q[q].gg, v[6]);
-                            v[7] = __builtin_fmaf(d_rgb, Q[q].gb, v[7]);
+                            v[5] = __builtin_fmaf(d_rgb, Q[qi].gr, v[5]);         // RAST:650
+                            v[6] = __builtin_fmaf(d_rgb, Q[qi].gg, v[6]);
+                            v[7] = __builtin_fmaf(d_rgb, Q[qi].gb, v[7]);
                             v[8] = __builtin_fmaf((ag * g) * (1.0f - apt), apt, v[8]);   // RAST:658-661
                             v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
                             v[10] += 1.0f;                                       // RAST:695-696
-                            Q[q].T = Tn;
+                            Q[qi].T = Tn;
                             const float wgt = alpha * Tn;
-                            Q[q].w0 = __builtin_fmaf(c4.x, wgt, Q[q].w0);        // RAST:656
-                            Q[q].w1 = __builtin_fmaf(c4.y, wgt, Q[q].w1);
-                            Q[q].w2 = __builtin_fmaf(c4.z, wgt, Q[q].w2);
-                            Q[q].tot0 += fabsf(vs0); Q[q].tot1 += fabsf(vs1);    // RAST:666-667
+                            Q[qi].w0 = __builtin_fmaf(c4.x, wgt, Q[qi].w0);        // RAST:656
+                            Q[qi].w1 = __builtin_fmaf(c4.y, wgt, Q[qi].w1);
+                            Q[qi].w2 = __builtin_fmaf(c4.z, wgt, Q[qi].w2);
+                            Q[qi].tot0 += fabsf(vs0); Q[qi].tot1 += fabsf(vs1);    // RAST:666-667
                         }
                     }
                     if (!any_use) continue;
@@ -179,10 +190,11 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     }
     if (mag_image) {                                                            // RAST:700-704
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int qi = 0; qi < NQ; ++qi) {
+            const int q = grp * NQ + qi;
             const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
             const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
-            mag_image[2 * o] = Q[q].tot0; mag_image[2 * o + 1] = Q[q].tot1;
+            mag_image[2 * o] = Q[qi].tot0; mag_image[2 * o + 1] = Q[qi].tot1;
         }
     }
 }
@@ -194,15 +206,15 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 // (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the
 // critical path of the launch.
 #define SUM_ROWS_SMALL 16
-__global__ __launch_bounds__(256) void k_sum_rows(int M, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
+__global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
                                                   const float* __restrict__ partial, const uint8_t* __restrict__ visited,
                                                   const float4* __restrict__ zero_row, float4* __restrict__ sums)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = m < M;
-    const uint32_t off = valid ? offsets[m] : 0u;
-    const int cnt = valid ? ntiles[m] : 0;
+    const uint32_t off = valid ? offsets[m] * (uint32_t)G : 0u;      // G rows per (point, tile) pair
+    const int cnt = valid ? ntiles[m] * G : 0;
     if (valid && cnt <= SUM_ROWS_SMALL) {
         const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)off * PW);
         const uint8_t* vis = visited + off;
@@ -427,9 +439,15 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
         (void)hipMemsetAsync(a.visited, 0, a.visited_bytes, s);      // flags + the shared all-zero row behind them
-        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<<<a.T, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets,
-                                                                           a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial,
-                                                                           a.visited, a.mag_image));
+        if (a.G == 1)
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
+        else if (a.G == 2)
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
+        else
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
@@ -437,7 +455,7 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
     if (a.M > 0)
-        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(a.M + 255) / 256, 256, 0, s>>>(a.M, a.offsets, a.ntiles, a.partial, a.visited,
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(a.M + 255) / 256, 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
                                                                                   a.zero_row, a.sums));
     GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.sums, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
