@@ -6,7 +6,8 @@
 
 Workload (BASELINE.json config 3, run as 1920x1088 -- SURVEY 8d): synth(5e5, 1920, 1088, 0.02, SH deg 3,
 seed 0), resident in HBM before the timed region.  A step = forward (projection, binning, sort, blend),
-dL/dimage = 2*(image-0.5), backward (blend backward, per-point chain); with N > 1 every rank renders its own
+dL/dimage = 2*(image-0.5), backward (blend backward, per-point chain, hook payload -- a no-op hook is
+installed like the reference trainer's controller.update); with N > 1 every rank renders its own
 view of the same scene and the ranks sum their point gradients with one RCCL all-reduce per step (weak scaling).
 Rank 0 prints ONE JSON line.  `roofline` is for the kernel that takes the most time, timed with HIP events
 recorded inside libgsrast on the launch stream during the timed region; `cpu_baseline` is the CPU oracle
@@ -58,6 +59,10 @@ def main():
     ap.add_argument("--workload", default="cfg3_headline")
     ap.add_argument("--mode", choices=["fwdbwd", "forward"], default=None,
                     help="forward = inference under torch.no_grad (BASELINE config 5); default: forward for cfg5, fwd+bwd otherwise")
+    ap.add_argument("--no-hook", dest="hook", action="store_false", default=True,
+                    help="by default a backward_valid_point_hook is installed, as the reference trainer does "
+                         "(GaussianPointTrainer.py:82-93), so the backward also produces the whole "
+                         "BackwardValidPointHookInput payload; --no-hook measures the operator without one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--breakdown-steps", type=int, default=10)
@@ -94,7 +99,9 @@ def main():
         camera_info=CameraInfo(torch.tensor(scene.camera_intrinsics, device=dev), H, W, 0),
         q_pointcloud_camera=torch.tensor(q, device=dev), t_pointcloud_camera=torch.tensor(t, device=dev),
         color_max_sh_band=3)
-    module = Rast(Rast.GaussianPointCloudRasterisationConfig())
+    hook_calls = []
+    module = Rast(Rast.GaussianPointCloudRasterisationConfig(),
+                  backward_valid_point_hook=(lambda payload: hook_calls.append(1)) if args.hook else None)
     L = _native.lib()
     names = L.gs_kernel_names().decode().split(",")
 
@@ -198,7 +205,8 @@ def main():
                        "points": N, "points_in_camera": M, "sort_pairs": K, "tiles": T, "sort_key_bits": key_bits,
                        "pixel_entry_evaluations": evals,
                        "parallelism": f"view-parallel x{world}",
-                       "collectives_per_step": (ncoll[-1] if ncoll else 0), "rehearsal": rehearsal},
+                       "collectives_per_step": (ncoll[-1] if ncoll else 0), "rehearsal": rehearsal,
+                       "backward_hook": bool(args.hook)},
             "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": dom[1], "model": KERNEL_MODEL_DOC},
