@@ -158,7 +158,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
 enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_SCAN_BLOCKS, KID_STORE_M, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
                   KID_SORT_HIST, KID_SCAN_REDUCE, KID_SCAN_APPLY, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
-                  KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_COUNT_ };
+                  KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
 void gs_prof_end(GsProf* p, int rec, hipStream_t s);
@@ -203,6 +203,7 @@ struct GsBlendFwdArgs {
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
+    int32_t* tile_work;            // (T) zeroed by the launcher; max over the tile's pixels of last - start
 };
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
 
@@ -210,6 +211,7 @@ struct GsBackwardArgs {
     GsProf* prof;
     int64_t N; int M; uint32_t K; int H, W, T;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
+    const int32_t* tile_work; int32_t* tile_order;   // scheduling: heaviest tiles first
     const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;

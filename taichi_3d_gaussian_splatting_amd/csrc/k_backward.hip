@@ -32,12 +32,50 @@
 // Pairs that are never visited (beyond every pixel's last index -- about three quarters of a
 // saturated tile's list -- or culled in all four quadrants) cost nothing: their rows are not
 // written and their `visited` byte stays 0 (the array is cleared by a memset per backward).
+// Tiles in order of decreasing backward work (entries to walk), so that the heaviest tiles are
+// dispatched first and the launch does not end on a few long-running waves.  Counting sort in one
+// workgroup: 2048 bins of width 1 (work >= 2047 shares the first bin).  Pure scheduling: results do
+// not depend on it.
+#define ORDER_BINS 2048
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order)
+{
+    __shared__ uint32_t bins[ORDER_BINS];
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
+    __syncthreads();
+    for (int i = t; i < T; i += 1024) {
+        int w = tile_work[i]; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+        atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);               // bin 0 = heaviest
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 bins (2 per thread)
+    uint32_t a = bins[2 * t], b = bins[2 * t + 1];
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint32_t excl = woff + incl - (a + b);
+    __syncthreads();
+    bins[2 * t] = excl; bins[2 * t + 1] = excl + a;
+    __syncthreads();
+    for (int i = t; i < T; i += 1024) {
+        int w = tile_work[i]; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+        const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
+        order[pos] = i;
+    }
+}
+
 struct QuadState { float T, w0, w1, w2, gr, gg, gb, tot0, tot1; int last; };
 
 // NQ = quadrants per wave: 4 (one wave per tile), 2 (two waves per tile, upper / lower half) or 1.
 // With G = 4/NQ waves per tile every (point, tile) pair owns G consecutive rows of `partial`.
 template <int NQ>
-__global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+__global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order,
+                                                       const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                        const int32_t* __restrict__ sorted_vals,
                                                        const float4* __restrict__ PA, const float4* __restrict__ PB,
                                                        const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
@@ -49,7 +87,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     __shared__ float4 sA[64], sB[64], sC[64];
     __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
     constexpr int G = 4 / NQ;
-    const int tile = blockIdx.x / G;
+    const int tile = tile_order[blockIdx.x / G];
     const int grp = blockIdx.x % G;               // which NQ quadrants of the tile this wave owns
     const int lane = threadIdx.x;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
@@ -439,14 +477,15 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
         (void)hipMemsetAsync(a.visited, 0, a.visited_bytes, s);      // flags + the shared all-zero row behind them
+        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order));
         if (a.G == 1)
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
                      a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
         else if (a.G == 2)
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
                      a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
         else
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
+            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
                      a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
     }
     else if (a.mag_image)

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
                                                    const float4* __restrict__ PC, int W, int tiles_x,
                                                    float* __restrict__ image, float* __restrict__ depth_out,
                                                    float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
-                                                   int32_t* __restrict__ count_out)
+                                                   int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work)
 {
     __shared__ float4 sA[4][64], sB[4][64], sC[4][64];
     const int tile = blockIdx.x;
@@ -84,16 +84,20 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         acc_alpha[o] = 1.0f - T_i;
         last_out[o] = last;
         count_out[o] = count;
+        // entries the backward will have to walk in this tile (largest last-effective index): scheduling hint only
+        const int wmax = gs_wave_max_i(last - start);
+        if (lane == 0 && wmax > 0) atomicMax(&tile_work[tile], wmax);
     }
 }
 
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
+    (void)hipMemsetAsync(a.tile_work, 0, sizeof(int32_t) * (size_t)a.T, s);
     if (a.rgb_only)
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
-                                                                             a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count));
+                                                                             a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
     else
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
-                                                                              a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count));
+                                                                              a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
 }
