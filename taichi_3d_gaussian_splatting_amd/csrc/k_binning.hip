@@ -97,20 +97,31 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys
     hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
 }
 
+// Stable scatter of one radix pass.  Per 4096-key tile: (1) every wave ranks its 1024 keys with
+// ballot matching (8 ballots -> lanes with the same digit -> rank = popcount of lower lanes) and
+// per-wave digit counters in LDS; (2) the tile's pairs are written to LDS in their sorted order;
+// (3) the block copies them out, so that each digit's run is written to HBM by consecutive lanes
+// (coalesced runs instead of 4-byte scatters).  Tiles of a block are processed in order with a
+// running global offset per digit, which keeps the pass stable.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out,
                                                       uint32_t n, int shift, const uint32_t* __restrict__ hist_scanned,
                                                       int nblocks, int tiles_per_block)
 {
-    __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t cnt[4][256];      // per-wave digit counts, then per-wave start inside the tile
+    __shared__ uint32_t gbase[256];       // running global offset of each digit for this block
+    __shared__ uint32_t dstart[256];      // start of each digit inside the sorted tile
+    __shared__ uint32_t wtot[4];
+    __shared__ KeyT skeys[SORT_TILE];
+    __shared__ int32_t svals[SORT_TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     gbase[t] = hist_scanned[t * nblocks + blockIdx.x];
     for (int tile = 0; tile < tiles_per_block; ++tile) {
-        uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tile) * SORT_TILE;
+        const uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tile) * SORT_TILE;
         if (tile_base >= n) break;
+        const uint32_t tile_n = (uint32_t)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
         cnt[0][t] = 0; cnt[1][t] = 0; cnt[2][t] = 0; cnt[3][t] = 0;
         __syncthreads();
         KeyT k[SORT_ROUNDS];
@@ -118,46 +129,67 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
         uint32_t rank[SORT_ROUNDS];
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
-            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            bool valid = i < n;
-            k[r] = valid ? keys_in[i] : (KeyT)0;
-            v[r] = valid ? vals_in[i] : 0;
+            const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            const bool valid = li < tile_n;
+            k[r] = valid ? keys_in[tile_base + li] : (KeyT)0;
+            v[r] = valid ? vals_in[tile_base + li] : 0;
         }
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
-            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            bool valid = i < n;
-            uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+            const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            const bool valid = li < tile_n;
+            const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
             unsigned long long same = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
-                bool b = (d >> bit) & 1u;
-                unsigned long long bal = __ballot(b);
+                const bool b = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(b);
                 same &= b ? bal : ~bal;
             }
-            uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
-            uint32_t before = valid ? cnt[wave][d] : 0u;
+            const uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
+            const uint32_t before = valid ? cnt[wave][d] : 0u;
             if (valid && in_round == 0) cnt[wave][d] = before + (uint32_t)__popcll(same);
             rank[r] = before + in_round;
         }
         __syncthreads();
-        {
-            uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
-            uint32_t g = gbase[t];
-            cnt[0][t] = g; cnt[1][t] = g + c0; cnt[2][t] = g + c0 + c1; cnt[3][t] = g + c0 + c1 + c2;
-            gbase[t] = g + c0 + c1 + c2 + c3;
+        // thread t owns digit t: tile total, exclusive scan over digits, per-wave starts
+        const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wtot[w];
+        const uint32_t ds = woff + incl - tot;
+        dstart[t] = ds;
+        cnt[0][t] = ds; cnt[1][t] = ds + c0; cnt[2][t] = ds + c0 + c1; cnt[3][t] = ds + c0 + c1 + c2;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ROUNDS; ++r) {
+            const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
+            if (li < tile_n) {
+                const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+                const uint32_t ipos = cnt[wave][d] + rank[r];
+                skeys[ipos] = k[r];
+                svals[ipos] = v[r];
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
-            uint64_t i = tile_base + (uint64_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            if (i < n) {
-                uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
-                uint32_t pos = cnt[wave][d] + rank[r];
-                keys_out[pos] = k[r];
-                vals_out[pos] = v[r];
+            const uint32_t idx = (uint32_t)r * 256u + t;
+            if (idx < tile_n) {
+                const KeyT kk = skeys[idx];
+                const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+                const uint32_t pos = gbase[d] + (idx - dstart[d]);
+                keys_out[pos] = kk;
+                vals_out[pos] = svals[idx];
             }
         }
+        __syncthreads();
+        gbase[t] += tot;
         __syncthreads();
     }
 }
