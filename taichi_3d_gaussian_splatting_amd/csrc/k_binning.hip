@@ -97,6 +97,57 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys
     hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
 }
 
+// The [digit][block] table of per-block counts becomes global offsets in two small launches:
+// k_sort_row_totals sums each digit's row; k_sort_rowscan (one block per digit) adds the totals of all
+// smaller digits to an exclusive scan along the digit's own row.  No atomics, fixed order.
+__global__ __launch_bounds__(256) void k_sort_row_totals(const uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
+{
+    __shared__ uint32_t wsum[4];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const uint32_t* row = hist + (size_t)d * nblocks;
+    uint32_t v = 0;
+    for (int i = t; i < nblocks; i += 256) v += row[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) totals[d] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void k_sort_rowscan(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+                                                       uint32_t* __restrict__ offsets_out, int nblocks)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t base_s;
+    const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v = (t < d) ? totals[t] : 0u;                      // d <= 255 < 1024 threads
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (t == 0) { uint32_t b = 0; for (int w = 0; w < 16; ++w) b += wsum[w]; base_s = b; }
+    __syncthreads();
+    uint32_t carry = base_s;
+    const uint32_t* row = hist + (size_t)d * nblocks;
+    uint32_t* orow = offsets_out + (size_t)d * nblocks;
+    for (int start = 0; start < nblocks; start += 1024) {
+        const int i = start + t;
+        const uint32_t x = i < nblocks ? row[i] : 0u;
+        uint32_t incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < nblocks) orow[i] = carry + woff + incl - x;
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        carry += tot;
+    }
+}
+
 // Stable scatter of one radix pass.  Per 4096-key tile: (1) every wave ranks its 1024 keys with
 // ballot matching (8 ballots -> lanes with the same digit -> rank = popcount of lower lanes) and
 // per-wave digit counters in LDS; (2) the tile's pairs are written to LDS in their sorted order;
@@ -224,7 +275,7 @@ size_t gs_sort_hist_elems(uint32_t K)
 {
     int nb, tpb;
     sort_geometry(K, &nb, &tpb);
-    return (size_t)256 * nb;
+    return (size_t)2 * 256 * nb;      // raw counts + scanned offsets
 }
 
 size_t gs_scan_tmp_elems(size_t n) { return 2 * ((n + GS_SCAN_CHUNK - 1) / GS_SCAN_CHUNK) + 16; }
@@ -245,9 +296,11 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     KeyT *kin = keys_a, *kout = keys_b;
     int32_t *vin = a.vals_a, *vout = a.vals_b;
     for (int shift = 0; shift < a.key_bits; shift += 8) {
+        uint32_t* offs = a.hist + (size_t)256 * nb;                 // second half of the table: scanned offsets
         GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
-        gs_scan_u32(a.hist, a.hist, 256 * nb, a.scan_tmp, nullptr, s, a.prof);
-        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, a.hist, nb, tpb));
+        GS_TIMED(a.prof, KID_SCAN_REDUCE, s, k_sort_row_totals<<<256, 256, 0, s>>>(a.hist, a.scan_tmp, nb));
+        GS_TIMED(a.prof, KID_SCAN_APPLY, s, k_sort_rowscan<<<256, 1024, 0, s>>>(a.hist, a.scan_tmp, offs, nb));
+        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, offs, nb, tpb));
         KeyT* tk = kin; kin = kout; kout = tk;
         int32_t* tv = vin; vin = vout; vout = tv;
     }
