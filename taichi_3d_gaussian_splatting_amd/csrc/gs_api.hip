@@ -48,12 +48,12 @@ struct DevBuf {
 
 // What RAST:998-1019 saves for backward, in this library's layouts (DESIGN.md "HBM layout").
 struct FrameBufs {
-    DevBuf mask, ids, cam_index, PA, PB, PC, PD, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, tile_end, pose, tile_work, tile_order;
+    DevBuf mask, ids, cam_index, PA, PB, PC, PD, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
     bool in_use = false;
     void release(int64_t* total)
     {
         DevBuf* all[] = { &mask, &ids, &cam_index, &PA, &PB, &PC, &PD, &box, &ntiles, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
-                          &tile_start, &tile_end, &pose, &tile_work, &tile_order };
+                          &tile_start, &pose, &tile_order };
         for (DevBuf* b : all) b->release(total);
     }
 };
@@ -263,8 +263,8 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
     ENSURE(B.PA, 16 * Np); ENSURE(B.PB, 16 * Np); ENSURE(B.PC, 16 * Np); ENSURE(B.PD, 16 * Np);
     ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.offsets, 4 * Np);
-    ENSURE(B.tile_start, 4 * (size_t)T); ENSURE(B.tile_end, 4 * (size_t)T);
-    ENSURE(B.tile_work, 4 * (size_t)T); ENSURE(B.tile_order, 4 * (size_t)T);
+    ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared by ONE memset
+    ENSURE(B.tile_order, 4 * (size_t)T);
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
     ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
     ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
@@ -310,7 +310,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     ba.keys_a = B.keys_a.p; ba.keys_b = B.keys_b.p; ba.key64 = key64;
     ba.vals_a = B.vals_a.as<int32_t>(); ba.vals_b = B.vals_b.as<int32_t>();
     ba.hist = c->hist.as<uint32_t>(); ba.scan_tmp = c->scan_tmp.as<uint32_t>();
-    ba.tile_start = B.tile_start.as<int32_t>(); ba.tile_end = B.tile_end.as<int32_t>(); ba.T = T;
+    ba.tile_start = B.tile_start.as<int32_t>(); ba.tile_end = B.tile_start.as<int32_t>() + T; ba.T = T;
     ba.keys_sorted = &f->keys_sorted; ba.vals_sorted = &f->vals_sorted;
     gs_launch_binning(ba, s);
     HIP_TRY_F(hipGetLastError());
@@ -322,7 +322,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
     fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;
-    fa.tile_work = B.tile_work.as<int32_t>();
+    fa.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)T;
     // tile ranges are all zero when K == 0, so the kernel writes the "no contributor" values itself
     gs_launch_blend_fwd(fa, s);
     HIP_TRY_F(hipGetLastError());
@@ -376,7 +376,7 @@ extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_
     a.ids = B.ids.as<int32_t>(); a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
     a.ntiles = B.ntiles.as<int32_t>(); a.offsets = B.offsets.as<uint32_t>();
     a.keys_sorted = f->keys_sorted; a.vals_sorted = f->vals_sorted;
-    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_end.as<int32_t>(); a.mask = B.mask.as<int8_t>();
+    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.mask = B.mask.as<int8_t>();
     a.dst = dst;
     gs_launch_export(a, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
@@ -425,8 +425,8 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.prof = &c->prof;
     a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = K;
     a.H = f->info.camera_height; a.W = f->info.camera_width; a.T = f->info.n_tiles;
-    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_end.as<int32_t>(); a.vals_sorted = f->vals_sorted;
-    a.tile_work = B.tile_work.as<int32_t>(); a.tile_order = B.tile_order.as<int32_t>();
+    a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.vals_sorted = f->vals_sorted;
+    a.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)f->info.n_tiles; a.tile_order = B.tile_order.as<int32_t>();
     a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
     a.box = B.box.as<ushort4>(); a.offsets = B.offsets.as<uint32_t>(); a.ntiles = B.ntiles.as<int32_t>();
     a.ids = B.ids.as<int32_t>(); a.cam_index = B.cam_index.as<int32_t>();

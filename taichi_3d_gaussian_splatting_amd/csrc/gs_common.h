@@ -203,7 +203,7 @@ struct GsBlendFwdArgs {
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
-    int32_t* tile_work;            // (T) zeroed by the launcher; max over the tile's pixels of last - start
+    int32_t* tile_work;            // (T) zeroed together with the tile ranges; max over the tile's pixels of last - start
 };
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
 

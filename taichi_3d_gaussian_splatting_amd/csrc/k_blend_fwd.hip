@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
-    (void)hipMemsetAsync(a.tile_work, 0, sizeof(int32_t) * (size_t)a.T, s);
     if (a.rgb_only)
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
                                                                              a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
