@@ -236,3 +236,54 @@ def test_cfg5_inference_2e6_forward_parity_and_properties(P):
     assert bool((tile_of_key[te[nonempty] - 1] == torch.nonzero(nonempty).flatten()).all())
     image, depth, count = outs
     assert float(image.min()) >= 0.0 and float(image.max()) <= 1.0 + 1e-5
+
+
+def test_several_frames_in_flight_and_arena_is_stable(P):
+    """Two forwards, then their backwards in reverse order (frames pin separate buffer sets); afterwards the
+    context allocates nothing more for repeated steps (grow-only arena, no hipMalloc in steady state)."""
+    import ctypes as C
+    from taichi_3d_gaussian_splatting_amd import _native
+    s1, s2 = synth(3000, 160, 96, 0.08, seed=21), synth(5000, 160, 96, 0.05, seed=22)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    i1, i2 = P.make_input(s1, q, t), P.make_input(s2, q, t)
+    f1, fa1 = P.run_oracle(s1, q, t)
+    f2, fa2 = P.run_oracle(s2, q, t)
+    o1 = module(i1)
+    o2 = module(i2)                                # second forward before the first backward
+    g2 = torch.ones_like(o2[0])
+    o2[0].backward(g2)
+    P.assert_backward_parity(module, i2, g2.cpu().numpy(), f2, 3)
+    g1 = torch.ones_like(o1[0])
+    o1[0].backward(g1)
+    P.assert_backward_parity(module, i1, g1.cpu().numpy(), f1, 3)
+    ctx = module._ctx_for(i1.point_cloud.device)
+    sizes = []
+    for _ in range(4):
+        inp = P.make_input(s2, q, t)
+        img = module(inp)[0]
+        img.sum().backward()
+        torch.cuda.synchronize()
+        sizes.append(_native.lib().gs_ctx_device_bytes(ctx))
+    assert sizes[1:] == sizes[:-1], sizes
+
+
+def test_forward_without_backward_releases_its_frame(P):
+    """A kept frame whose autograd graph is dropped (no backward) goes back to the pool."""
+    import gc
+    s = synth(2000, 128, 96, 0.08, seed=23)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    from taichi_3d_gaussian_splatting_amd import _native
+    ctx = None
+    sizes = []
+    for _ in range(6):
+        inp = P.make_input(s, q, t)
+        out = module(inp)
+        ctx = module._ctx_for(inp.point_cloud.device)
+        del out, inp
+        module.last_frame = None
+        gc.collect()
+        torch.cuda.synchronize()
+        sizes.append(_native.lib().gs_ctx_device_bytes(ctx))
+    assert sizes[-1] == sizes[1], sizes              # the pool stops growing: dropped frames are reused
