@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -94,6 +94,19 @@ typedef struct gs_frame_info {
     int32_t kept_for_backward;
 } gs_frame_info;
 
+/* Optional: the six per-point accumulators of the adaptive density controller
+ * (GaussianPointAdaptiveController.py:114-127), updated IN PLACE (+=) for every in-camera point exactly as
+ * GaussianPointAdaptiveController.update() does from the hook payload (:133-141), so that the statistics
+ * need neither the hook gathers nor six torch scatter-adds.  All device arrays with N rows. */
+typedef struct gs_controller_accumulators {
+    int32_t* accumulated_num_in_camera;                      /* (N)   += 1 */
+    int32_t* accumulated_num_pixels;                         /* (N)   += num_affected_pixels */
+    float*   accumulated_view_space_position_gradients;      /* (N)   += magnitude_grad_viewspace */
+    float*   accumulated_view_space_position_gradients_avg;  /* (N)   += magnitude / num_affected_pixels (0 when 0/0) */
+    float*   accumulated_position_gradients;                 /* (N,3) += grad_pointcloud row */
+    float*   accumulated_position_gradients_norm;            /* (N)   += |grad_pointcloud row|_2 */
+} gs_controller_accumulators;
+
 /* Outputs of backward, RAST:1051-1067 + RAST:1127-1140.  The first two are
  * mandatory; every other pointer may be NULL (need_extra_info = false).
  * All N-row arrays are fully written (rows outside the frustum = 0). */
@@ -109,6 +122,7 @@ typedef struct gs_backward_out {
     float*   hook_grad_pointfeatures_in_camera; /* device (M,56) */
     float*   hook_grad_viewspace;               /* device (M,2)  */
     float*   hook_magnitude_grad_viewspace;     /* device (M)    */
+    const gs_controller_accumulators* controller; /* host pointer to a struct of device arrays, or NULL */
 } gs_backward_out;
 
 /* Intermediates a frame can copy out, in the reference's layouts (saved tensors

@@ -15,6 +15,7 @@ import torch
 
 from . import _native
 from .Camera import CameraInfo
+from .controller_stats import ControllerAccumulators
 
 TILE_WIDTH = 16
 TILE_HEIGHT = 16
@@ -129,11 +130,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         point_uv_in_camera: torch.Tensor  # Mx2
 
     def __init__(self, config: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationConfig",
-                 backward_valid_point_hook: Optional[Callable[["GaussianPointCloudRasterisation.BackwardValidPointHookInput"], None]] = None):
+                 backward_valid_point_hook: Optional[Callable[["GaussianPointCloudRasterisation.BackwardValidPointHookInput"], None]] = None,
+                 controller_accumulators: Optional[ControllerAccumulators] = None):
+        """`controller_accumulators` is an extension over the reference signature (RAST:819-824): when given, every
+        backward adds this view's densification statistics to them on the device (controller_stats.py)."""
         super().__init__()
         _native.lib()                       # fail now, loudly, if libgsrast.so is absent
         self.config = config
         self._hook = backward_valid_point_hook
+        self.controller_accumulators = controller_accumulators
         self._ctxs = {}                     # device index -> gs_ctx*
         self.last_frame: Optional[_Frame] = None   # inspection aid (tests / profiling); replaced every call
         self.last_forward_outputs = {}
@@ -261,8 +266,17 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         h_feat = e(M, 56) if want_hook else None
         h_uv = e(M, 2) if want_hook else None
         h_mag = e(M) if want_hook else None
+        ctrl = None
+        if self.controller_accumulators is not None:
+            ca = self.controller_accumulators
+            ca.validate(N, dev)
+            ctrl = _native.GsControllerAccumulators(
+                _ptr(ca.accumulated_num_in_camera), _ptr(ca.accumulated_num_pixels),
+                _ptr(ca.accumulated_view_space_position_gradients), _ptr(ca.accumulated_view_space_position_gradients_avg),
+                _ptr(ca.accumulated_position_gradients), _ptr(ca.accumulated_position_gradients_norm))
         out = _native.GsBackwardOut(_ptr(grad_pc), _ptr(grad_feat), _ptr(grad_uv), _ptr(mag), _ptr(mag_img), _ptr(n_aff),
-                                    _ptr(h_pc), _ptr(h_feat), _ptr(h_uv), _ptr(h_mag))
+                                    _ptr(h_pc), _ptr(h_feat), _ptr(h_uv), _ptr(h_mag),
+                                    C.pointer(ctrl) if ctrl is not None and N > 0 else None)
         scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):

@@ -3,3 +3,4 @@ Wenri/taichi_3d_gaussian_splatting.  Importing the package does 
 load the HIP library; constructing the operator does, and fails loudly without it."""
 from .Camera import CameraInfo  # noqa: F401
 from .GaussianPointCloudRasterisation import GaussianPointCloudRasterisation  # noqa: F401
+from .controller_stats import ControllerAccumulators  # noqa: F401

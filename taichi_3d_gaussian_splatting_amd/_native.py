@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -41,12 +41,19 @@ class GsFrameInfo(C.Structure):
                 ("kept_for_backward", _I32)]
 
 
+class GsControllerAccumulators(C.Structure):
+    _fields_ = [("accumulated_num_in_camera", _VP), ("accumulated_num_pixels", _VP),
+                ("accumulated_view_space_position_gradients", _VP),
+                ("accumulated_view_space_position_gradients_avg", _VP),
+                ("accumulated_position_gradients", _VP), ("accumulated_position_gradients_norm", _VP)]
+
+
 class GsBackwardOut(C.Structure):
     _fields_ = [("grad_pointcloud", _VP), ("grad_pointcloud_features", _VP), ("grad_viewspace", _VP),
                 ("magnitude_grad_viewspace", _VP), ("magnitude_grad_viewspace_on_image", _VP),
                 ("num_affected_pixels", _VP), ("hook_grad_point_in_camera", _VP),
                 ("hook_grad_pointfeatures_in_camera", _VP), ("hook_grad_viewspace", _VP),
-                ("hook_magnitude_grad_viewspace", _VP)]
+                ("hook_magnitude_grad_viewspace", _VP), ("controller", C.POINTER(GsControllerAccumulators))]
 
 
 # gs_export ids (include/gs_rasterizer.h) -> (name, numpy/torch dtype name, trailing shape)

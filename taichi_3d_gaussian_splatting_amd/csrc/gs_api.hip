@@ -446,6 +446,14 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.n_affected = out->num_affected_pixels;
     a.hook_gpc = out->hook_grad_point_in_camera; a.hook_gfeat = out->hook_grad_pointfeatures_in_camera;
     a.hook_guv = out->hook_grad_viewspace; a.hook_mag = out->hook_magnitude_grad_viewspace;
+    if (const gs_controller_accumulators* ca = out->controller) {
+        if (!ca->accumulated_num_in_camera || !ca->accumulated_num_pixels || !ca->accumulated_view_space_position_gradients ||
+            !ca->accumulated_view_space_position_gradients_avg || !ca->accumulated_position_gradients || !ca->accumulated_position_gradients_norm)
+            return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: controller accumulators must all be given");
+        a.c_num_in_camera = ca->accumulated_num_in_camera; a.c_num_pixels = ca->accumulated_num_pixels;
+        a.c_vs_grad = ca->accumulated_view_space_position_gradients; a.c_vs_grad_avg = ca->accumulated_view_space_position_gradients_avg;
+        a.c_pos_grad = ca->accumulated_position_gradients; a.c_pos_grad_norm = ca->accumulated_position_gradients_norm;
+    }
     gs_launch_backward(a, s);
     HIP_TRY(hipGetLastError());
     return GS_OK;

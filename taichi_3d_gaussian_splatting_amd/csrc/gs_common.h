@@ -225,6 +225,8 @@ struct GsBackwardArgs {
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
     float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;
     float* hook_gpc; float* hook_gfeat; float* hook_guv; float* hook_mag;
+    // adaptive-controller accumulators (CTRL:114-141), all nullable together
+    int32_t* c_num_in_camera; int32_t* c_num_pixels; float* c_vs_grad; float* c_vs_grad_avg; float* c_pos_grad; float* c_pos_grad_norm;
 };
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s);
 

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     int keep, float f_color, float f_high, float f_s, float f_q, float f_alpha,
     float* __restrict__ grad_pc, float* __restrict__ grad_feat, float* __restrict__ grad_uv, float* __restrict__ mag,
     int32_t* __restrict__ n_affected,
-    float* __restrict__ hook_gpc, float* __restrict__ hook_gfeat, float* __restrict__ hook_guv, float* __restrict__ hook_mag)
+    float* __restrict__ hook_gpc, float* __restrict__ hook_gfeat, float* __restrict__ hook_guv, float* __restrict__ hook_mag,
+    int32_t* __restrict__ c_num_in_camera, int32_t* __restrict__ c_num_pixels, float* __restrict__ c_vs_grad,
+    float* __restrict__ c_vs_grad_avg, float* __restrict__ c_pos_grad, float* __restrict__ c_pos_grad_norm)
 {
     int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
@@ -471,6 +473,16 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     }
     if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
     if (hook_mag) hook_mag[m] = s[9];
+    if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
+        const int32_t npix = (int32_t)(s[10] + 0.5f);
+        c_num_in_camera[n] += 1;
+        c_num_pixels[n] += npix;
+        c_vs_grad[n] += s[9];
+        const float avg = s[9] / (float)npix;                       // 0/0 -> NaN -> 0 (CTRL:138-139); x/0 -> inf is kept
+        c_vs_grad_avg[n] += (avg != avg) ? 0.0f : avg;
+        c_pos_grad[3 * n] += gt[0]; c_pos_grad[3 * n + 1] += gt[1]; c_pos_grad[3 * n + 2] += gt[2];
+        c_pos_grad_norm[n] += sqrtf(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
+    }
 }
 
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
@@ -499,5 +511,6 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.sums, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
                                                                     a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
-                                                                    a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag));
+                                                                    a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag,
+                                                                    a.c_num_in_camera, a.c_num_pixels, a.c_vs_grad, a.c_vs_grad_avg, a.c_pos_grad, a.c_pos_grad_norm));
 }

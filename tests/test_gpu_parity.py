@@ -287,3 +287,46 @@ def test_forward_without_backward_releases_its_frame(P):
         torch.cuda.synchronize()
         sizes.append(_native.lib().gs_ctx_device_bytes(ctx))
     assert sizes[-1] == sizes[1], sizes              # the pool stops growing: dropped frames are reused
+
+
+def test_controller_accumulators_match_reference_update(P):
+    """the six accumulators of GaussianPointAdaptiveController.update() (reference
+    GaussianPointAdaptiveController.py:130-141) maintained by the backward kernel, against a numpy restatement of
+    those lines applied to the oracle's hook quantities, over two views."""
+    from taichi_3d_gaussian_splatting_amd import ControllerAccumulators
+    s = synth(4000, 160, 96, 0.08, sh_deg=3, seed=31)
+    N = 4000
+    acc = ControllerAccumulators.zeros(N, P.DEV)
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig(), controller_accumulators=acc)
+    ref = dict(num_in_camera=np.zeros(N, np.int64), num_pixels=np.zeros(N, np.int64), vs=np.zeros(N), vs_avg=np.zeros(N),
+               pos=np.zeros((N, 3)), pos_norm=np.zeros(N))
+    for v in range(2):
+        q, t = view_pose(v, 2)
+        inp = P.make_input(s, q, t)
+        f, _ = P.run_oracle(s, q, t)
+        img = module(inp)[0]
+        g = 2.0 * (img.detach() - 0.5)
+        img.backward(g)
+        b = oracle.backward(f, g.cpu().numpy(), 3)
+        ids = f.point_id_in_camera_list
+        npix = b["num_affected_pixels"].astype(np.int64)
+        mag = b["magnitude_grad_viewspace"][ids].astype(np.float64)
+        ref["num_in_camera"][ids] += 1                                    # :133
+        ref["num_pixels"][ids] += npix                                    # :134
+        ref["vs"][ids] += mag                                             # :135-136
+        with np.errstate(divide="ignore", invalid="ignore"):
+            avg = mag / npix                                              # :137
+        avg[np.isnan(avg)] = 0                                            # :138
+        ref["vs_avg"][ids] += avg                                         # :139
+        gp = b["grad_pointcloud"][ids].astype(np.float64)
+        ref["pos"][ids] += gp                                             # :140
+        ref["pos_norm"][ids] += np.linalg.norm(gp, axis=1)                # :141
+    assert np.array_equal(acc.accumulated_num_in_camera.cpu().numpy(), ref["num_in_camera"])
+    assert np.array_equal(acc.accumulated_num_pixels.cpu().numpy(), ref["num_pixels"])
+    for got, want in [(acc.accumulated_view_space_position_gradients, ref["vs"]),
+                      (acc.accumulated_view_space_position_gradients_avg, ref["vs_avg"]),
+                      (acc.accumulated_position_gradients, ref["pos"]),
+                      (acc.accumulated_position_gradients_norm, ref["pos_norm"])]:
+        assert P.rel_err(got.cpu().numpy().astype(np.float64), want) < P.GRAD_TOL
+    acc.reset()
+    assert not acc.accumulated_num_in_camera.any() and not acc.accumulated_position_gradients.any()

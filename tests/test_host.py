@@ -88,3 +88,18 @@ def test_operator_rejects_bad_arguments_before_touching_the_gpu():
         m(mk())
     with pytest.raises(TypeError):
         m(mk(point_cloud=torch.tensor(s.point_cloud).double()))
+
+
+def test_controller_accumulators_container():
+    """Attribute names and dtypes of the reference controller's accumulators (GaussianPointAdaptiveController.py:114-127)."""
+    from taichi_3d_gaussian_splatting_amd import ControllerAccumulators
+    acc = ControllerAccumulators.zeros(10, "cpu")
+    assert acc.accumulated_num_in_camera.dtype == torch.int32 and acc.accumulated_num_pixels.dtype == torch.int32
+    assert acc.accumulated_position_gradients.shape == (10, 3) and acc.accumulated_position_gradients_norm.shape == (10,)
+    acc.validate(10, "cpu")
+    with pytest.raises(ValueError):
+        acc.validate(11, "cpu")
+    acc.accumulated_view_space_position_gradients += 1
+    acc.reset()
+    assert not acc.accumulated_view_space_position_gradients.any()
+    acc.all_reduce()          # no process group: a no-op
