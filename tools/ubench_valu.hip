@@ -10,6 +10,8 @@ __global__ void k(float* out, int iters)
 {
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float m = 1.0001f, c = 0.5f;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pm = {m, m}, pc = {c, c};
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {          // 8 independent fma chains
 #pragma unroll
@@ -56,6 +58,18 @@ __global__ void k(float* out, int iters)
                              "v_cmp_lt_f32 vcc, %4, %5\n v_cndmask_b32 %4, %4, %5, vcc\n v_cmp_lt_f32 vcc, %6, %7\n v_cndmask_b32 %6, %6, %7, vcc\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
             }
+        } else if (MODE == 7) {   // 4 independent v_pk_fma_f32 (2 floats per lane each)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
+            }
+        } else if (MODE == 8) {   // 4 independent v_pk_mul_f32
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm));
+            }
         } else if (MODE == 6) {   // 8 independent v_mul_f32 (2-operand)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -64,7 +78,7 @@ __global__ void k(float* out, int iters)
             }
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y;
 }
 
 template <int MODE>
@@ -86,16 +100,16 @@ double run(int waves_per_simd, int iters, float* d)
 int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
-    const char* names[] = { "fma x8 independent", "fma dependent chain", "add_dpp quad_perm x8", "add_dpp row_bcast x8", "v_exp x8", "cmp+cndmask x4", "v_mul x8" };
+    const char* names[] = { "fma x8 independent", "fma dependent chain", "add_dpp quad_perm x8", "add_dpp row_bcast x8", "v_exp x8", "cmp+cndmask x4", "v_mul x8", "v_pk_fma x4 (64 instr/iter)", "v_pk_mul x4 (64 instr/iter)" };
     const int iters = 20000;
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         printf("%-24s", names[mode]);
         for (int w : { 1, 2, 4, 8 }) {
             double s = 0;
             switch (mode) {
             case 0: s = run<0>(w, iters, d); break; case 1: s = run<1>(w, iters, d); break; case 2: s = run<2>(w, iters, d); break;
             case 3: s = run<3>(w, iters, d); break; case 4: s = run<4>(w, iters, d); break; case 5: s = run<5>(w, iters, d); break;
-            case 6: s = run<6>(w, iters, d); break;
+            case 6: s = run<6>(w, iters, d); break; case 7: s = run<7>(w, iters, d); break; case 8: s = run<8>(w, iters, d); break;
             }
             printf("  w=%d: %.2f ns/instr/SIMD (%.2f cyc @2.4GHz)", w, s * 1e9, s * 2.4e9);
         }
