@@ -9,6 +9,10 @@
 #include "gs_common.h"
 #include "gs_scan.h"
 
+#ifndef GS_RADIUS_FROM_PREBLUR_COV
+#define GS_RADIUS_FROM_PREBLUR_COV 1
+#endif
+
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4])
 {   // UTIL:403-413
@@ -219,8 +223,15 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
             for (int k = 1; k < 16; ++k) acc = acc + f[k] * sh[k];
             col[ch] = gs_sigmoid(acc);
         }
-        // ---- radius from the pre-blur covariance, RAST:311-315 ----
-        float large_eigen = (c00 + c11 + sqrtf((c00 - c11) * (c00 - c11) + 4.0f * c01 * c10)) / 2.0f;
+        // ---- radius, RAST:311-315.  Taichi passes the mat2 to get_point_conic_and_rescale by value, so the radius
+        // sees the covariance BEFORE the +0.3 blur.  The switch mirrors the oracle's
+        // radius_from_preblur_cov in case a comparison against real Taichi output ever says otherwise. ----
+#if GS_RADIUS_FROM_PREBLUR_COV
+        const float e00 = c00, e11 = c11;
+#else
+        const float e00 = b00, e11 = b11;
+#endif
+        float large_eigen = (e00 + e11 + sqrtf((e00 - e11) * (e00 - e11) + 4.0f * c01 * c10)) / 2.0f;
         float radii = sqrtf(large_eigen) * 3.0f;
         // ---- tile box + count, RAST:81-128 ----
         int box[4];
