@@ -88,27 +88,14 @@ __device__ __forceinline__ void gs_tile_box(float u, float v, float radii, int t
 }
 
 // wave64 helpers -----------------------------------------------------------------
-__device__ __forceinline__ int gs_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
 __device__ __forceinline__ float gs_dpp(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
 }
 
-// Sum over the 64 lanes; the total is valid in lanes 48..63 (all of row 3).
-__device__ __forceinline__ float gs_wave_sum_row3(float v)
-{
-    v += gs_dpp<0xB1>(v);              // quad_perm [1,0,3,2]
-    v += gs_dpp<0x4E>(v);              // quad_perm [2,3,0,1]
-    v += gs_dpp<0x141>(v);             // row_half_mirror
-    v += gs_dpp<0x140>(v);             // row_mirror
-    v += gs_dpp<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
-    v += gs_dpp<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-// The same reduction for 11 values at once, written as v_add_f32_dpp so that every step is ONE
+// Sum of eleven values over the 64 lanes (totals valid in lanes 48..63, all of row 3): six DPP steps
+// (quad_perm x2, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31), written as v_add_f32_dpp so that every step is ONE
 // instruction per value (hipcc lowers the builtin form to v_mov_dpp + add, and to three
 // instructions for the row_bcast steps).  A DPP source written by the previous VALU instruction
 // needs two wait states: each step starts with s_nop 1; inside a step the eleven registers

@@ -1,8 +1,10 @@
-"""First GPU run: cfg1 through the operator, compare against the oracle step by step, print."""
+"""Diagnostic: run one BASELINE config through the operator on cuda:0, compare every product with the CPU oracle
+and print per-array exactness plus rough fwd/bwd wall times.  usage: python tools/gpu_first_light.py [cfg1_plumbing|cfg3_headline|...]"""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_util as P
 from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose
 from oracle import oracle
