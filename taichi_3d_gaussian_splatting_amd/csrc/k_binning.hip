@@ -88,10 +88,20 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys
     __shared__ uint32_t lh[256];
     lh[threadIdx.x] = 0;
     __syncthreads();
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * SORT_TILE;
+    const uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * SORT_TILE;     // multiple of 4096: 16-byte aligned
     uint64_t end = begin + (uint64_t)tiles_per_block * SORT_TILE;
     if (end > n) end = n;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += 256)
+    // four keys per load (16 or 32 bytes per lane), then four LDS atomics
+    constexpr int V = 4;
+    struct alignas(sizeof(KeyT) * V) KeyVec { KeyT k[V]; };
+    const uint64_t nvec = begin < end ? (end - begin) / V : 0;
+    const KeyVec* kv = reinterpret_cast<const KeyVec*>(keys + begin);
+    for (uint64_t i = threadIdx.x; i < nvec; i += 256) {
+        const KeyVec x = kv[i];
+#pragma unroll
+        for (int j = 0; j < V; ++j) atomicAdd(&lh[(uint32_t)(x.k[j] >> shift) & 255u], 1u);
+    }
+    for (uint64_t i = begin + nvec * V + threadIdx.x; i < end; i += 256)
         atomicAdd(&lh[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     __syncthreads();
     hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
