@@ -330,3 +330,20 @@ def test_controller_accumulators_match_reference_update(P):
         assert P.rel_err(got.cpu().numpy().astype(np.float64), want) < P.GRAD_TOL
     acc.reset()
     assert not acc.accumulated_num_in_camera.any() and not acc.accumulated_position_gradients.any()
+
+
+def test_heavy_tile_lists_and_clustered_scene(P):
+    """A scene unlike the uniform generator: 1500 image-filling splats on top of 30k small ones (every tile list is
+    thousands of entries long, most pairs come from the wave-cooperative keygen / row-sum paths), a dense cluster,
+    points hugging the near plane and a camera translated into the cloud."""
+    rng = np.random.default_rng(77)
+    s = synth(31500, 640, 368, 0.03, sh_deg=3, seed=77)
+    s.point_cloud_features[:1500, 4:7] = np.log(rng.uniform(1.0, 4.0, (1500, 3))).astype(np.float32)   # huge
+    s.point_cloud_features[:1500, 7] = rng.uniform(-4.0, -1.0, 1500).astype(np.float32)                # faint, so lists stay long
+    s.point_cloud[1500:6500] = (np.array([0.3, -0.2, 3.0]) + rng.normal(0, 0.05, (5000, 3))).astype(np.float32)   # cluster
+    s.point_cloud[6500:7500, 2] = rng.uniform(0.75, 0.85, 1000).astype(np.float32)                      # around near_plane = 0.8
+    q = np.array([[0.01, -0.02, 0.03, 1.0]], np.float32)
+    t = np.array([[0.05, 0.02, 1.0]], np.float32)
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=5)
+    lens = f.tile_points_end - f.tile_points_start
+    assert lens.max() > 1500 and f.num_overlap_tiles.max() > 500
