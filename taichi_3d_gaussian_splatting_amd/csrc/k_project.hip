@@ -35,12 +35,10 @@ __device__ __forceinline__ void rotation_from_quaternion(const float q[4], float
     R[6] = 2.0f * (xz - wy);        R[7] = 2.0f * (yz + wx);        R[8] = 1.0f - 2.0f * (xx + yy);
 }
 
-__global__ void k_pose_prepare(const float* __restrict__ q_pc, const float* __restrict__ t_pc, int n, GsPose* __restrict__ pose,
-                               GsCounters* __restrict__ counters)
+// Pose record of one object: inverse_SE3_qt_torch (UTIL:426-432) + rotation_matrix_from_quaternion (GP3D:30-48)
+// + the camera centre as taichi_inverse_SE3 computes it (UTIL:495-510).
+__device__ __forceinline__ GsPose make_pose(const float* __restrict__ q_pc, const float* __restrict__ t_pc, int i)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { counters->M = 0; counters->K = 0; counters->max_depth_code = 0; counters->reserved = 0; }
-    if (i >= n) return;
     float qc[4] = { -q_pc[4 * i], -q_pc[4 * i + 1], -q_pc[4 * i + 2], q_pc[4 * i + 3] };
     float nrm = sqrtf(qc[0] * qc[0] + qc[1] * qc[1] + qc[2] * qc[2] + qc[3] * qc[3]);
     float qn[4] = { qc[0] / nrm, qc[1] / nrm, qc[2] / nrm, qc[3] / nrm };
@@ -52,13 +50,22 @@ __global__ void k_pose_prepare(const float* __restrict__ q_pc, const float* __re
     GsPose p;
     rotation_from_quaternion(qc, p.R);
     p.t[0] = -rot[0]; p.t[1] = -rot[1]; p.t[2] = -rot[2];
-    // taichi_inverse_SE3 translation: (-R^T) @ t, UTIL:495-510
     float RTn[9] = { -p.R[0], -p.R[3], -p.R[6], -p.R[1], -p.R[4], -p.R[7], -p.R[2], -p.R[5], -p.R[8] };
     gs_mm<3, 3, 1>(RTn, p.t, p.origin_fwd);
     p.origin_bwd[0] = t_pc[3 * i]; p.origin_bwd[1] = t_pc[3 * i + 1]; p.origin_bwd[2] = t_pc[3 * i + 2];
     p.q_cp[0] = qc[0]; p.q_cp[1] = qc[1]; p.q_cp[2] = qc[2]; p.q_cp[3] = qc[3];
     p.pad[0] = p.pad[1] = 0.0f;
-    pose[i] = p;
+    return p;
+}
+
+// Host prologue of the reference (RAST:841-846) on the device: one pose record per object; also clears the
+// frame counters.  Launched alone only when the scene is empty; otherwise k_filter's first block does it.
+__global__ void k_pose_prepare(const float* __restrict__ q_pc, const float* __restrict__ t_pc, int n, GsPose* __restrict__ pose,
+                               GsCounters* __restrict__ counters)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counters->M = 0; counters->K = 0; counters->max_depth_code = 0; counters->reserved = 0; }
+    if (i < n) pose[i] = make_pose(q_pc, t_pc, i);
 }
 
 // project_point_to_camera, GP3D:14-27 (T = [R|t; 0 0 0 1])
@@ -75,17 +82,29 @@ __device__ __forceinline__ void project_point(const float* __restrict__ R, const
 }
 
 // ---------------------------------------------------------------------------------
+#define FILTER_POSE_CACHE 8
 __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, const int8_t* __restrict__ invalid,
                                                 const int32_t* __restrict__ obj, const float* __restrict__ Kmat,
-                                                const GsPose* __restrict__ pose, int64_t N, int W, int H,
-                                                float near_plane, float far_plane,
+                                                const float* __restrict__ q_pc, const float* __restrict__ t_pc, int n_objects,
+                                                GsPose* __restrict__ pose, GsCounters* __restrict__ counters,
+                                                int64_t N, int W, int H, float near_plane, float far_plane,
                                                 int8_t* __restrict__ mask, int32_t* __restrict__ block_counts)
 {
     __shared__ int wave_cnt[4];
+    __shared__ GsPose sp[FILTER_POSE_CACHE];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // every block derives the (few) pose records itself -- same arithmetic as the stored ones -- so that no separate
+    // pose launch has to finish first; block 0 stores them for the later kernels and clears the frame counters
+    const bool cached = n_objects <= FILTER_POSE_CACHE;
+    if (cached && threadIdx.x < n_objects) sp[threadIdx.x] = make_pose(q_pc, t_pc, threadIdx.x);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { counters->M = 0; counters->K = 0; counters->max_depth_code = 0; counters->reserved = 0; }
+        for (int o = threadIdx.x; o < n_objects; o += 256) pose[o] = make_pose(q_pc, t_pc, o);
+    }
+    __syncthreads();
     bool in = false;
     if (i < N && invalid[i] != 1) {
-        const GsPose& P = pose[obj[i]];
+        const GsPose P = cached ? sp[obj[i]] : make_pose(q_pc, t_pc, obj[i]);
         float Km[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Km[k] = Kmat[k];
@@ -104,20 +123,30 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-__global__ __launch_bounds__(256) void k_compact(const int8_t* __restrict__ mask, const int32_t* __restrict__ block_offsets,
-                                                 int64_t N, int32_t* __restrict__ ids, int32_t* __restrict__ cam_index)
+// Every block sums the counts of the blocks before it (a few thousand L2-resident ints) instead of waiting for a
+// separate scan launch; the last block also publishes M.
+__global__ __launch_bounds__(256) void k_compact(const int8_t* __restrict__ mask, const int32_t* __restrict__ block_counts,
+                                                 int64_t N, int32_t* __restrict__ ids, int32_t* __restrict__ cam_index,
+                                                 GsCounters* __restrict__ counters)
 {
     __shared__ int wave_cnt[4];
+    __shared__ int wave_pre[4];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool in = i < N && mask[i] != 0;
     unsigned long long b = __ballot(in);
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    int pre = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) pre += block_counts[j];
+    pre = gs_wave_sum_i(pre);
+    if (lane == 0) { wave_cnt[wave] = __popcll(b); wave_pre[wave] = pre; }
     __syncthreads();
+    const int block_offset = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3];
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
     int rank = __popcll(b & ((1ull << lane) - 1ull));
-    int m = block_offsets[blockIdx.x] + woff + rank;
+    int m = block_offset + woff + rank;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        counters->M = block_offset + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     if (in) ids[m] = (int32_t)i;
     if (i < N) cam_index[i] = in ? m : -1;
 }
@@ -264,14 +293,14 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
 {
     const int nb = (int)((a.N + 255) / 256);
-    GS_TIMED(a.prof, KID_POSE, s, k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters));
-    if (nb == 0) return;
-    GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.pose, a.N, a.W, a.H,
-                                                            a.near_plane, a.far_plane, a.mask, a.block_counts));
-    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(reinterpret_cast<const uint32_t*>(a.block_counts),
-                                                                      reinterpret_cast<uint32_t*>(a.block_offsets), nb,
-                                                                      reinterpret_cast<uint32_t*>(&a.counters->M)));
-    GS_TIMED(a.prof, KID_COMPACT, s, k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_offsets, a.N, a.ids, a.cam_index));
+    if (nb == 0) {
+        GS_TIMED(a.prof, KID_POSE, s, k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters));
+        return;
+    }
+    GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.q_pc, a.t_pc, a.n_objects,
+                                                            a.pose, a.counters, a.N, a.W, a.H, a.near_plane, a.far_plane, a.mask,
+                                                            a.block_counts));
+    GS_TIMED(a.prof, KID_COMPACT, s, k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_counts, a.N, a.ids, a.cam_index, a.counters));
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters));
