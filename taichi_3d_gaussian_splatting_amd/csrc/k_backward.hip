@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                                                        const int32_t* __restrict__ last_in, int W, int tiles_x,
                                                        float* __restrict__ partial, uint8_t* __restrict__ visited, float* __restrict__ mag_image)
 {
-    __shared__ float4 sA[64], sB[64], sC[64];
+    __shared__ float4 sRec[64][3];             // the batch's splat records
     __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
     constexpr int G = 4 / NQ;
     const int tile = tile_order[blockIdx.x / G];
@@ -137,12 +137,12 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     const ushort4 bx = boxes[p];
                     slot = (offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z))) * G + grp;
                 }
-                sA[lane] = A; sB[lane] = B; sC[lane] = C;
+                sRec[lane][0] = A; sRec[lane][1] = B; sRec[lane][2] = C;
                 __builtin_amdgcn_wave_barrier();
                 while (U) {
                     const int j = 63 - __builtin_clzll(U);                    // back to front, RAST:605-608
                     U &= ~(1ull << j);
-                    const float4 a4 = sA[j], b4 = sB[j], c4 = sC[j];
+                    const float4 a4 = sRec[j][0], b4 = sRec[j][1], c4 = sRec[j][2];
                     const float a = a4.z, b = a4.w, c = b4.x, apt = b4.z;
                     float v[11];
 #pragma unroll

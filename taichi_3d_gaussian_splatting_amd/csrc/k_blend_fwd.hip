@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
                                                    float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
                                                    int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work)
 {
-    __shared__ float4 sA[4][64], sB[4][64], sC[4][64];
+    __shared__ float4 sRec[4][64][3];          // the batch's splat records, one slab per wave
     const int tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), rx0, ry0);
         unsigned long long mask = __ballot(keep);
         if (mask == 0ull) continue;
-        sA[wave][lane] = A; sB[wave][lane] = B; sC[wave][lane] = C;
+        sRec[wave][lane][0] = A; sRec[wave][lane][1] = B; sRec[wave][lane][2] = C;
         __builtin_amdgcn_wave_barrier();
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1ull;
-            const float4 a4 = sA[wave][j], b4 = sB[wave][j], c4 = sC[wave][j];
+            const float4 a4 = sRec[wave][j][0], b4 = sRec[wave][j][1], c4 = sRec[wave][j][2];
             // get_point_probability_density_from_conic_and_rescale, UTIL:275-284 (same op order)
             float dx = px - a4.x, dy = py - a4.y;
             float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
                 if (!RGB_ONLY) { acc_d += b4.w * alpha * T_i; norm += alpha * T_i; count += 1; } // RAST:464-469
                 T_i = next_T;
             }
-            if (__ballot(!saturated) == 0ull) { mask = 0ull; }
+            if (__ballot(sat_now) != 0ull && __ballot(!saturated) == 0ull) { mask = 0ull; }   // re-test only when a lane just saturated
         }
         __builtin_amdgcn_wave_barrier();
     }
