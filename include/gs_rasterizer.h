@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -179,6 +179,23 @@ int gs_backward(gs_ctx* ctx, gs_frame* frame, const gs_scene* scene, const gs_ca
                 int32_t color_max_sh_band, const gs_backward_out* out, gs_stream stream);
 
 int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
+
+/* ---- the step either side of the operator in the reference's training loop ---------------- */
+
+/* L = (1 - lambda) * L1 + lambda * (1 - SSIM), LossFunction.py:20-38, with SSIM as pytorch_msssim.ssim(
+ * data_range=1, size_average=True): forward value AND d L / d predicted_image in three launches.
+ * Both images are device (3,H,W) f32 contiguous, the layout GaussianPointTrainer.py:173-181 hands to the loss
+ * (already clamped to [0,1] and permuted).  loss_terms: device float[3] = {L, L1, LD_SSIM}.
+ * grad_predicted: device (3,H,W) or NULL.  H and W must be at least 11.  The scale regulariser of
+ * LossFunction.py:40-51 is not part of this call. */
+int gs_loss_l1_ssim(gs_ctx* ctx, const float* predicted_image, const float* ground_truth_image, int32_t height, int32_t width,
+                    float lambda_value, float* loss_terms, float* grad_predicted, gs_stream stream);
+
+/* One torch.optim.Adam step (betas, eps; no weight decay, no amsgrad) on a flat device f32 tensor of n
+ * elements, replacing optimizer.step() / position_optimizer.step() of GaussianPointTrainer.py:131-134,183-184.
+ * `step` is the 1-based step count used for the bias corrections. */
+int gs_adam_step(gs_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, int64_t step, gs_stream stream);
 
 /* Bytes of device memory the context currently owns (arena + frames). */
 int64_t gs_ctx_device_bytes(const gs_ctx* ctx);

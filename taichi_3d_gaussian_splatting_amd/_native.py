@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -78,7 +78,8 @@ EXPORTS = {
 # every symbol include/gs_rasterizer.h declares
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
-           "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read"]
+           "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
+           "gs_loss_l1_ssim", "gs_adam_step"]
 
 _lib = None
 
@@ -126,6 +127,8 @@ def lib():
     L.gs_frame_release.argtypes = [_VP, _VP]
     L.gs_ctx_device_bytes.argtypes = [_VP]
     L.gs_profile_enable.argtypes = [_VP, C.c_uint64]
+    L.gs_loss_l1_ssim.argtypes = [_VP, _VP, _VP, _I32, _I32, _F32, _VP, _VP, _VP]
+    L.gs_adam_step.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _I64, _VP]
     L.gs_profile_read.argtypes = [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32, _I32]
     L.gs_ctx_device_bytes.restype = _I64
     if L.gs_abi_version() != ABI_VERSION:
@@ -138,3 +141,15 @@ def check(rc, what):
     if rc != 0:
         msg = lib().gs_last_error()
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+_shared_ctx = {}
+
+
+def shared_ctx(device_index: int):
+    """A process-wide gs_ctx per device for the stateless helpers (loss, Adam)."""
+    if device_index not in _shared_ctx:
+        h = C.c_void_p()
+        check(lib().gs_create(device_index, C.byref(h)), "gs_create")
+        _shared_ctx[device_index] = h
+    return _shared_ctx[device_index]

@@ -107,7 +107,7 @@ struct gs_ctx {
     std::vector<gs_frame*> frames;      // every handle ever issued (recycled)
     gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
-    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums;
+    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums, loss_ws;
     GsCounters* host_counters = nullptr;   // pinned
 };
 
@@ -145,7 +145,7 @@ extern "C" int gs_destroy(gs_ctx* c)
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
     for (gs_frame* f : c->frames) delete f;
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
-                      &c->counters, &c->partial, &c->visited, &c->sums };
+                      &c->counters, &c->partial, &c->visited, &c->sums, &c->loss_ws };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
@@ -455,6 +455,32 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
         a.c_pos_grad = ca->accumulated_position_gradients; a.c_pos_grad_norm = ca->accumulated_position_gradients_norm;
     }
     gs_launch_backward(a, s);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_loss_l1_ssim(gs_ctx* c, const float* pred, const float* gt, int32_t H, int32_t W, float lambda_value,
+                               float* loss_terms, float* grad_pred, gs_stream stream_)
+{
+    if (!c || !pred || !gt || !loss_terms) return fail(GS_ERR_INVALID_ARGUMENT, "gs_loss_l1_ssim: NULL argument");
+    if (H < 11 || W < 11) return fail(GS_ERR_INVALID_ARGUMENT, "gs_loss_l1_ssim: image smaller than the 11x11 SSIM window");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = c->loss_ws.ensure(gs_loss_workspace_floats(H, W) * sizeof(float), &c->device_bytes);
+    if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_loss_l1_ssim: workspace");
+    gs_launch_loss(pred, gt, H, W, lambda_value, c->loss_ws.as<float>(), loss_terms, grad_pred, reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_adam_step(gs_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                            float lr, float beta1, float beta2, float eps, int64_t step, gs_stream stream_)
+{
+    if (!c || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return fail(GS_ERR_INVALID_ARGUMENT, "gs_adam_step: NULL argument");
+    if (n < 0 || step < 1) return fail(GS_ERR_INVALID_ARGUMENT, "gs_adam_step: n must be >= 0 and step >= 1");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    gs_launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }

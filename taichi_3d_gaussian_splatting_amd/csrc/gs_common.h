@@ -221,3 +221,8 @@ struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_b
     const int32_t* ids; const float4 *PA, *PB, *PC, *PD; const int32_t* ntiles; const uint32_t* offsets;
     const void* keys_sorted; const int32_t* vals_sorted; const int32_t *tile_start, *tile_end; const int8_t* mask; void* dst; };
 void gs_launch_export(const GsExportArgs& a, hipStream_t s);
+
+size_t gs_loss_workspace_floats(int H, int W);
+void gs_launch_loss(const float* X, const float* Y, int H, int W, float lambda, float* workspace, float* terms, float* grad, hipStream_t s);
+void gs_launch_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int64_t step, hipStream_t s);

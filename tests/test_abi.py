@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "gs_rasterizer.h")
 def _declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gs_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
