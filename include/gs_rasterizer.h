@@ -191,6 +191,15 @@ int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
 int gs_loss_l1_ssim(gs_ctx* ctx, const float* predicted_image, const float* ground_truth_image, int32_t height, int32_t width,
                     float lambda_value, float* loss_terms, float* grad_predicted, gs_stream stream);
 
+/* Scale regulariser of LossFunction.py:40-51: mean over valid points (point_invalid_mask == 0) of
+ * || exp(features[:, 4:7]) ||_2.  value_and_count: device float[2] = {mean, number of valid points}. */
+int gs_scale_regulariser(gs_ctx* ctx, const float* point_cloud_features, const int8_t* point_invalid_mask, int64_t n_points,
+                         float* value_and_count, gs_stream stream);
+/* Its gradient: writes the whole (N,56) array (zero outside columns 4:7 and for invalid rows), scaled by the
+ * device scalar *upstream; value_and_count is the output of gs_scale_regulariser for the same inputs. */
+int gs_scale_regulariser_grad(gs_ctx* ctx, const float* point_cloud_features, const int8_t* point_invalid_mask, int64_t n_points,
+                              const float* value_and_count, const float* upstream, float* grad_features, gs_stream stream);
+
 /* One torch.optim.Adam step (betas, eps; no weight decay, no amsgrad) on a flat device f32 tensor of n
  * elements, replacing optimizer.step() / position_optimizer.step() of GaussianPointTrainer.py:131-134,183-184.
  * `step` is the 1-based step count used for the bias corrections. */

@@ -3,7 +3,8 @@
 with the L1 + SSIM part (value and gradient) computed by libgsrast in three HIP launches
 (gs_loss_l1_ssim) instead of pytorch_msssim's conv2d chain + autograd.  SSIM follows
 pytorch_msssim.ssim(data_range=1, size_average=True): 11-tap Gaussian window (sigma 1.5), valid filtering,
-K1 = 0.01, K2 = 0.03.  The scale regulariser stays in torch (a handful of ops on an (N,3) slice)."""
+K1 = 0.01, K2 = 0.03.  The scale regulariser is fused as well (gs_scale_regulariser[_grad]): in torch its
+boolean-mask indexing and the sort-based index_put of its backward cost more than the rasteriser's backward."""
 import ctypes as C
 from dataclasses import dataclass
 
@@ -47,6 +48,39 @@ class _L1SSIM(torch.autograd.Function):
         return grad * grad_loss, None, None
 
 
+class _ScaleRegulariser(torch.autograd.Function):
+    """mean over valid points of ||exp(s)||_2 (LossFunction.py:40-51) without boolean-mask indexing."""
+
+    @staticmethod
+    def forward(ctx, features, invalid_mask):
+        if features.dtype != torch.float32 or not features.is_cuda or not features.is_contiguous() or features.shape[1] != 56:
+            raise TypeError("pointcloud_features must be a contiguous float32 (N,56) GPU tensor")
+        mask = invalid_mask if invalid_mask.dtype == torch.int8 else invalid_mask.to(torch.int8)
+        dev = features.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs_scale_regulariser(
+                _native.shared_ctx(idx), C.c_void_p(features.data_ptr()), C.c_void_p(mask.data_ptr()), features.shape[0],
+                C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gs_scale_regulariser")
+        ctx.save_for_backward(features, mask, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        features, mask, out = ctx.saved_tensors
+        dev = features.device
+        grad = torch.empty_like(features)
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs_scale_regulariser_grad(
+                _native.shared_ctx(idx), C.c_void_p(features.data_ptr()), C.c_void_p(mask.data_ptr()), features.shape[0],
+                C.c_void_p(out.data_ptr()), C.c_void_p(up.data_ptr()), C.c_void_p(grad.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gs_scale_regulariser_grad")
+        return grad, None
+
+
 class LossFunction(nn.Module):
     @dataclass
     class LossFunctionConfig(_ConfigBase):
@@ -73,5 +107,8 @@ class LossFunction(nn.Module):
         return L, L1, LD_SSIM
 
     def _regularization_loss(self, point_invalid_mask, pointcloud_features):
+        if pointcloud_features.is_cuda and pointcloud_features.dtype == torch.float32 and pointcloud_features.is_contiguous() \
+                and pointcloud_features.dim() == 2 and pointcloud_features.shape[1] == 56:
+            return _ScaleRegulariser.apply(pointcloud_features, point_invalid_mask)
         s = pointcloud_features[point_invalid_mask == 0, 4:7]           # LossFunction.py:48-50
         return torch.norm(torch.exp(s), dim=1).mean()

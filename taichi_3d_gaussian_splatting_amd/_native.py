@@ -79,7 +79,7 @@ EXPORTS = {
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
            "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
-           "gs_loss_l1_ssim", "gs_adam_step"]
+           "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad"]
 
 _lib = None
 
@@ -128,6 +128,8 @@ def lib():
     L.gs_ctx_device_bytes.argtypes = [_VP]
     L.gs_profile_enable.argtypes = [_VP, C.c_uint64]
     L.gs_loss_l1_ssim.argtypes = [_VP, _VP, _VP, _I32, _I32, _F32, _VP, _VP, _VP]
+    L.gs_scale_regulariser.argtypes = [_VP, _VP, _VP, _I64, _VP, _VP]
+    L.gs_scale_regulariser_grad.argtypes = [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]
     L.gs_adam_step.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _I64, _VP]
     L.gs_profile_read.argtypes = [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32, _I32]
     L.gs_ctx_device_bytes.restype = _I64

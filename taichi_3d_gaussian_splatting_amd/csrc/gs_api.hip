@@ -473,6 +473,32 @@ extern "C" int gs_loss_l1_ssim(gs_ctx* c, const float* pred, const float* gt, in
     return GS_OK;
 }
 
+extern "C" int gs_scale_regulariser(gs_ctx* c, const float* feat, const int8_t* mask, int64_t n, float* out, gs_stream stream_)
+{
+    if (!c || !out || (n > 0 && (!feat || !mask))) return fail(GS_ERR_INVALID_ARGUMENT, "gs_scale_regulariser: NULL argument");
+    if (n < 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_scale_regulariser: n_points < 0");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = c->loss_ws.ensure((size_t)(2 * ((n + 255) / 256) + 16) * sizeof(float), &c->device_bytes);
+    if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_scale_regulariser: workspace");
+    gs_launch_reg_value(feat, mask, n, c->loss_ws.as<float>(), out, reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_scale_regulariser_grad(gs_ctx* c, const float* feat, const int8_t* mask, int64_t n, const float* value_and_count,
+                                         const float* upstream, float* grad, gs_stream stream_)
+{
+    if (!c || (n > 0 && (!feat || !mask || !value_and_count || !upstream || !grad)))
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_scale_regulariser_grad: NULL argument");
+    if (grad && ((uintptr_t)grad & 15u) != 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_scale_regulariser_grad: grad must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    gs_launch_reg_grad(feat, mask, n, value_and_count, upstream, grad, reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
 extern "C" int gs_adam_step(gs_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                             float lr, float beta1, float beta2, float eps, int64_t step, gs_stream stream_)
 {

@@ -226,3 +226,6 @@ size_t gs_loss_workspace_floats(int H, int W);
 void gs_launch_loss(const float* X, const float* Y, int H, int W, float lambda, float* workspace, float* terms, float* grad, hipStream_t s);
 void gs_launch_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int64_t step, hipStream_t s);
+void gs_launch_reg_value(const float* feat, const int8_t* invalid, int64_t N, float* workspace, float* out, hipStream_t s);
+void gs_launch_reg_grad(const float* feat, const int8_t* invalid, int64_t N, const float* value_and_count, const float* upstream,
+                        float* grad, hipStream_t s);

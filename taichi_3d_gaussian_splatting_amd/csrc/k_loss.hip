@@ -204,6 +204,90 @@ void gs_launch_loss(const float* X, const float* Y, int H, int W, float lambda, 
 }
 
 // ---------------------------------------------------------------------------------
+// Scale regulariser, LossFunction.py:40-51: mean over valid points of || exp(s) ||_2, s = features[:, 4:7].
+// In torch the boolean-mask indexing and its backward (a sort-based index_put) cost more than the rasteriser's
+// whole backward; here: one pass for the value (per-block partials + fixed-order finish, which also leaves the
+// number of valid points on the device) and one pass that writes the dense (N,56) gradient.
+__global__ __launch_bounds__(256) void k_reg_partials(const float* __restrict__ feat, const int8_t* __restrict__ invalid, int64_t N,
+                                                      float* __restrict__ psum, float* __restrict__ pcnt)
+{
+    __shared__ float ws[2][4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.0f, c = 0.0f;
+    if (i < N && invalid[i] == 0) {
+        const float* r = feat + (size_t)GS_NFEAT * i + 4;
+        const float e0 = gs_expf(r[0]), e1 = gs_expf(r[1]), e2 = gs_expf(r[2]);
+        v = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        c = 1.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = v; ws[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        psum[blockIdx.x] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]);
+        pcnt[blockIdx.x] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_reg_finish(const float* __restrict__ psum, const float* __restrict__ pcnt, int n,
+                                                     float* __restrict__ out /* [0] = mean norm, [1] = number of valid points */)
+{
+    __shared__ double ws[2][16];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = t; i < n; i += 1024) { a += (double)psum[i]; b += (double)pcnt[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((t & 63) == 0) { ws[0][t >> 6] = a; ws[1][t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+        double sa = 0.0, sb = 0.0;
+        for (int w = 0; w < 16; ++w) { sa += ws[0][w]; sb += ws[1][w]; }
+        out[0] = (float)(sa / sb);           // 0/0 -> NaN like torch's mean of an empty tensor
+        out[1] = (float)sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reg_grad(const float* __restrict__ feat, const int8_t* __restrict__ invalid, int64_t N,
+                                                  const float* __restrict__ value_and_count, const float* __restrict__ upstream,
+                                                  float* __restrict__ grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float4* g4 = reinterpret_cast<float4*>(grad + (size_t)GS_NFEAT * i);
+    float gs0 = 0.0f, gs1 = 0.0f, gs2 = 0.0f;
+    if (invalid[i] == 0) {
+        const float* r = feat + (size_t)GS_NFEAT * i + 4;
+        const float e0 = gs_expf(r[0]), e1 = gs_expf(r[1]), e2 = gs_expf(r[2]);
+        const float nrm = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float k = upstream[0] / (value_and_count[1] * nrm);       // d mean||e|| / d s_j = e_j^2 / (||e|| count)
+        gs0 = k * e0 * e0; gs1 = k * e1 * e1; gs2 = k * e2 * e2;
+    }
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    g4[0] = z;
+    g4[1] = make_float4(gs0, gs1, gs2, 0.0f);
+#pragma unroll
+    for (int k = 2; k < GS_NFEAT / 4; ++k) g4[k] = z;
+}
+
+void gs_launch_reg_value(const float* feat, const int8_t* invalid, int64_t N, float* workspace, float* out, hipStream_t s)
+{
+    const int nb = (int)((N + 255) / 256);
+    if (nb == 0) { (void)hipMemsetAsync(out, 0, 2 * sizeof(float), s); return; }
+    k_reg_partials<<<nb, 256, 0, s>>>(feat, invalid, N, workspace, workspace + nb);
+    k_reg_finish<<<1, 1024, 0, s>>>(workspace, workspace + nb, nb, out);
+}
+
+void gs_launch_reg_grad(const float* feat, const int8_t* invalid, int64_t N, const float* value_and_count, const float* upstream,
+                        float* grad, hipStream_t s)
+{
+    const int nb = (int)((N + 255) / 256);
+    if (nb == 0) return;
+    k_reg_grad<<<nb, 256, 0, s>>>(feat, invalid, N, value_and_count, upstream, grad);
+}
+
+// ---------------------------------------------------------------------------------
 // torch.optim.Adam(betas, eps, no weight decay, no amsgrad) on a flat f32 tensor: one fused update.
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
                                               float* __restrict__ exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,

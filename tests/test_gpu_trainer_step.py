@@ -63,6 +63,10 @@ def test_regulariser_and_reference_call_shapes():
     assert torch.allclose(L, 0.8 * L1 + 0.2 * LD + 2 * reg, rtol=1e-6)
     L.backward()
     assert pred.grad is not None and feat.grad is not None and not feat.grad[mask == 1].any()
+    f64 = feat.detach().double().requires_grad_(True)
+    (2 * torch.norm(torch.exp(f64[mask == 0, 4:7]), dim=1).mean()).backward()
+    assert torch.allclose(feat.grad, f64.grad.float(), rtol=1e-5, atol=1e-9)
+    assert not feat.grad[:, :4].any() and not feat.grad[:, 7:].any()
 
 
 def test_fused_adam_matches_torch_adam():
