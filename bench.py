@@ -63,6 +63,8 @@ def main():
                     help="by default a backward_valid_point_hook is installed, as the reference trainer does "
                          "(GaussianPointTrainer.py:82-93), so the backward also produces the whole "
                          "BackwardValidPointHookInput payload; --no-hook measures the operator without one")
+    ap.add_argument("--scene", default=None, help="a trained scene file (.parquet in the reference's layout or an INRIA .ply) to "
+                    "render instead of the synthetic generator's points; camera and resolution still come from --workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--breakdown-steps", type=int, default=10)
@@ -88,6 +90,12 @@ def main():
     mode = args.mode or ("forward" if args.workload.startswith("cfg5") else "fwdbwd")
     cfgw = CONFIGS[args.workload]
     scene = synth(**cfgw)
+    if args.scene:
+        from taichi_3d_gaussian_splatting_amd import scene_io
+        pc_np, ft_np = (scene_io.load_inria_ply if args.scene.endswith(".ply") else scene_io.load_parquet)(args.scene)
+        scene.point_cloud, scene.point_cloud_features = pc_np, ft_np
+        scene.point_invalid_mask = np.zeros(pc_np.shape[0], np.int8)
+        scene.point_object_id = np.zeros(pc_np.shape[0], np.int32)
     q, t = view_pose(rank, world)
     H, W = scene.height, scene.width
     pc = torch.tensor(scene.point_cloud, device=dev, requires_grad=True)
@@ -199,7 +207,7 @@ def main():
             "value": round(world * args.steps / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": ("synthetic" if not args.scene else "file:" + os.path.basename(args.scene)),
             "config": {"workload": f"{args.workload}: synth(N={cfgw['N']}, {W}x{H}, sigma0={cfgw['sigma0']}, sh_deg={cfgw['sh_deg']}, seed 0), "
                                    f"{'fwd+bwd' if mode == 'fwdbwd' else 'forward only (torch.no_grad)'}, one view per GPU, sum all-reduce of 59*N f32 point gradients when N>1",
                        "points": N, "points_in_camera": M, "sort_pairs": K, "tiles": T, "sort_key_bits": key_bits,
