@@ -51,6 +51,8 @@ typedef struct gs_config {
     float   grad_s_factor;                   /* 0.5   */
     float   grad_q_factor;                   /* 1     */
     float   grad_alpha_factor;               /* 20    */
+    int32_t allow_partial_tiles;             /* 0; EXTENSION: 1 lifts the W,H % 16 == 0 requirement (RAST:1193-1194): tile
+                                                counts are rounded up and pixels outside the image do not exist */
 } gs_config;
 
 /* The point-cloud half of GaussianPointCloudRasterisationInput, RAST:788-804. */
@@ -68,7 +70,7 @@ typedef struct gs_camera {
     const float* t_pointcloud_camera;       /* device (n_objects,3) */
     int32_t      n_objects;
     const float* camera_intrinsics;         /* device (3,3) row-major */
-    int32_t      camera_height;             /* multiples of 16 (RAST:1193-1194) */
+    int32_t      camera_height;             /* multiples of 16 (RAST:1193-1194) unless gs_config.allow_partial_tiles */
     int32_t      camera_width;
 } gs_camera;
 

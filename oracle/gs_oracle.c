@@ -327,14 +327,20 @@ void gso_conic_and_rescale(const float cov_in[4], float out[4])
 }
 
 /* RAST:81-103 */
+static void bounding_box_tiles(float u, float v, float radii, int32_t tiles_u, int32_t tiles_v, int32_t box[4]);
+
 void gso_bounding_box(float u, float v, float radii, int W, int H, int32_t box[4])
+{
+    bounding_box_tiles(u, v, radii, W / GSO_TILE, H / GSO_TILE, box);
+}
+
+static void bounding_box_tiles(float u, float v, float radii, int32_t tiles_u, int32_t tiles_v, int32_t box[4])
 {
     radii = max_f(radii, 1.0f);
     float min_u = max_f(0.0f, u - radii);
     float max_u = u + radii;
     float min_v = max_f(0.0f, v - radii);
     float max_v = v + radii;
-    int32_t tiles_u = W / GSO_TILE, tiles_v = H / GSO_TILE;
     int32_t min_tile_u = (int32_t)floorf(min_u / (float)GSO_TILE);
     min_tile_u = min_i(min_tile_u, tiles_u);
     int32_t max_tile_u = (int32_t)floorf(max_u / (float)GSO_TILE) + 1;
@@ -429,10 +435,12 @@ gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, cons
                        int64_t N, const float* q_pc, const float* t_pc, int32_t n_obj,
                        const float* Km, int32_t H, int32_t W, const gso_config* cfg)
 {
-    if (W % GSO_TILE != 0 || H % GSO_TILE != 0 || n_obj <= 0) return NULL;  /* RAST:1193-1194 */
+    if (W <= 0 || H <= 0 || n_obj <= 0) return NULL;
+    if (!cfg->allow_partial_tiles && (W % GSO_TILE != 0 || H % GSO_TILE != 0)) return NULL;  /* RAST:1193-1194 */
     gso_frame* f = (gso_frame*)zalloc(sizeof(gso_frame));
     f->N = N; f->H = H; f->W = W; f->n_objects = n_obj;
-    f->tiles_x = W / GSO_TILE; f->tiles_y = H / GSO_TILE; f->T = f->tiles_x * f->tiles_y;
+    f->tiles_x = (W + GSO_TILE - 1) / GSO_TILE; f->tiles_y = (H + GSO_TILE - 1) / GSO_TILE;   /* = W/16, H/16 for the reference's sizes */
+    f->T = f->tiles_x * f->tiles_y;
     f->q_camera_pointcloud = (float*)zalloc(sizeof(float) * 4 * n_obj);
     f->t_camera_pointcloud = (float*)zalloc(sizeof(float) * 3 * n_obj);
     gso_inverse_se3_qt(q_pc, t_pc, n_obj, f->q_camera_pointcloud, f->t_camera_pointcloud); /* RAST:845 */
@@ -508,7 +516,7 @@ gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, cons
         f->point_radii[idx] = radii;
         /* ---- step 3: generate_num_overlap_tiles, RAST:106-128 ---- */
         int32_t box[4];
-        gso_bounding_box(uv[0], uv[1], radii, W, H, box);
+        bounding_box_tiles(uv[0], uv[1], radii, f->tiles_x, f->tiles_y, box);
         f->num_overlap_tiles[idx] = (box[1] - box[0]) * (box[3] - box[2]);
     }
     /* RAST:913-922 exclusive scan */
@@ -525,13 +533,13 @@ gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, cons
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int64_t p = 0; p < M; ++p) {
         int32_t box[4];
-        gso_bounding_box(f->point_uv[2 * p], f->point_uv[2 * p + 1], f->point_radii[p], W, H, box);
+        bounding_box_tiles(f->point_uv[2 * p], f->point_uv[2 * p + 1], f->point_radii[p], f->tiles_x, f->tiles_y, box);
         int32_t enc_depth = (int32_t)(f->point_in_camera[3 * p + 2] * scale);
         for (int32_t tu = box[0]; tu < box[1]; ++tu)
             for (int32_t tv = box[2]; tv < box[3]; ++tv) {
                 int32_t cnt = (box[3] - box[2]) * (tu - box[0]) + (tv - box[2]);
                 int64_t key_idx = f->accumulated_num_overlap_tiles[p] + cnt;
-                int32_t tile_id = tu + tv * (W / GSO_TILE);
+                int32_t tile_id = tu + tv * f->tiles_x;
                 f->sort_key_unsorted[key_idx] = (int64_t)enc_depth + (((int64_t)tile_id) << 32);
                 f->point_offset_unsorted[key_idx] = (int32_t)p;
             }
@@ -562,6 +570,7 @@ gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, cons
         for (int32_t t = 0; t < GSO_TILE * GSO_TILE; ++t) {
             int32_t pixel_u = tile_u * GSO_TILE + t % GSO_TILE;
             int32_t pixel_v = tile_v * GSO_TILE + t / GSO_TILE;
+            if (pixel_u >= W || pixel_v >= H) continue;          /* partial tile (extension) */
             float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
             float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
             float acc_depth = 0.0f, depth_norm = 0.0f;
@@ -634,6 +643,7 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
         for (int32_t t = 0; t < GSO_TILE * GSO_TILE; ++t) {
             int32_t pixel_u = tile_u * GSO_TILE + t % GSO_TILE;
             int32_t pixel_v = tile_v * GSO_TILE + t / GSO_TILE;
+            if (pixel_u >= f->W || pixel_v >= f->H) continue;          /* partial tile (extension) */
             size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
             int32_t last = f->pixel_offset_of_last_effective_point[o];
             float accumulated_alpha = f->pixel_accumulated_alpha[o];

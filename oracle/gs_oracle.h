@@ -45,6 +45,8 @@ typedef struct gso_config {
     float grad_q_factor;                 /* RAST:785 (1)   */
     float grad_alpha_factor;             /* RAST:786 (20)  */
     int   radius_from_preblur_cov;   /* SURVEY 8a a5-vii switch; 1 = Taichi by-value semantics */
+    int   allow_partial_tiles;       /* EXTENSION (not in the reference, which asserts W,H % 16 == 0): the last tile
+                                        row/column may be partly outside the image; tile counts are rounded up */
 } gso_config;
 
 /* Everything the forward produces, in the reference's own layouts. */

@@ -23,13 +23,13 @@ class Config(C.Structure):
         ("depth_to_sort_key_scale", C.c_float), ("rgb_only", C.c_int),
         ("grad_color_factor", C.c_float), ("grad_high_order_color_factor", C.c_float),
         ("grad_s_factor", C.c_float), ("grad_q_factor", C.c_float),
-        ("grad_alpha_factor", C.c_float), ("radius_from_preblur_cov", C.c_int),
+        ("grad_alpha_factor", C.c_float), ("radius_from_preblur_cov", C.c_int), ("allow_partial_tiles", C.c_int),
     ]
 
 
 def default_config(**kw):
     """Reference defaults, GaussianPointCloudRasterisation.py:776-786."""
-    c = Config(0.8, 1000.0, 100.0, 0, 5.0, 1.0, 0.5, 1.0, 20.0, 1)
+    c = Config(0.8, 1000.0, 100.0, 0, 5.0, 1.0, 0.5, 1.0, 20.0, 1, 0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -104,6 +104,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         grad_s_factor = 0.5
         grad_q_factor = 1.
         grad_alpha_factor = 20.
+        # extension over the reference: True lifts the W,H % 16 == 0 requirement (e.g. a true 1920x1080 frame)
+        allow_partial_tiles = False
 
     @dataclass
     class GaussianPointCloudRasterisationInput:
@@ -191,7 +193,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         c = self.config
         return _native.GsConfig(c.near_plane, c.far_plane, c.depth_to_sort_key_scale, 1 if c.rgb_only else 0,
                                 c.grad_color_factor, c.grad_high_order_color_factor, c.grad_s_factor,
-                                c.grad_q_factor, c.grad_alpha_factor)
+                                c.grad_q_factor, c.grad_alpha_factor, 1 if getattr(c, "allow_partial_tiles", False) else 0)
 
     @staticmethod
     def _c_scene(pointcloud, features, mask, obj):
@@ -297,8 +299,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
     # ------------------------------------------------------------------ nn.Module
     def forward(self, input_data: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput"):
         camera_info = input_data.camera_info
-        assert camera_info.camera_width % TILE_WIDTH == 0        # RAST:1193-1194
-        assert camera_info.camera_height % TILE_HEIGHT == 0
+        if not getattr(self.config, "allow_partial_tiles", False):
+            assert camera_info.camera_width % TILE_WIDTH == 0        # RAST:1193-1194
+            assert camera_info.camera_height % TILE_HEIGHT == 0
         return self._module_function.apply(
             input_data.point_cloud, input_data.point_cloud_features, input_data.point_invalid_mask,
             input_data.point_object_id, input_data.q_pointcloud_camera, input_data.t_pointcloud_camera,

@@ -17,7 +17,8 @@ _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 class GsConfig(C.Structure):
     _fields_ = [("near_plane", _F32), ("far_plane", _F32), ("depth_to_sort_key_scale", _F32),
                 ("rgb_only", _I32), ("grad_color_factor", _F32), ("grad_high_order_color_factor", _F32),
-                ("grad_s_factor", _F32), ("grad_q_factor", _F32), ("grad_alpha_factor", _F32)]
+                ("grad_s_factor", _F32), ("grad_q_factor", _F32), ("grad_alpha_factor", _F32),
+                ("allow_partial_tiles", _I32)]
 
 
 class GsScene(C.Structure):

@@ -231,9 +231,11 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
 {
     if (!c || !sc || !cam || !cfg || !out || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL argument");
     const int H = cam->camera_height, W = cam->camera_width;
-    if (W <= 0 || H <= 0 || W % GS_TILE != 0 || H % GS_TILE != 0)        // RAST:1193-1194
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: camera_width and camera_height must be positive multiples of 16");
-    if (W / GS_TILE > 65535 || H / GS_TILE > 65535) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: image too large");
+    if (W <= 0 || H <= 0 || (!cfg->allow_partial_tiles && (W % GS_TILE != 0 || H % GS_TILE != 0)))        // RAST:1193-1194
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: camera_width and camera_height must be positive multiples of 16 "
+                                             "(or set gs_config.allow_partial_tiles)");
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    if (tiles_x > 65535 || tiles_y > 65535) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: image too large");
     const int64_t N = sc->n_points;
     if (N < 0 || N >= (int64_t)1 << 31) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_points out of range");
     if (cam->n_objects <= 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_objects must be >= 1");
@@ -256,7 +258,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     gs_frame* f = acquire_frame(c);
     f->bufs = acquire_bufs(c);
     FrameBufs& B = *f->bufs;
-    const int T = (W / GS_TILE) * (H / GS_TILE);
+    const int T = tiles_x * tiles_y;
     const size_t nb = (size_t)((N + 255) / 256);
     const size_t Np = (size_t)(N > 0 ? N : 1);
 
@@ -303,7 +305,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
 
     GsBinArgs ba{};
     ba.prof = &c->prof;
-    ba.N = N; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.depth_scale = cfg->depth_to_sort_key_scale;
+    ba.N = N; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
     ba.offsets = B.offsets.as<uint32_t>();
@@ -317,7 +319,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
 
     GsBlendFwdArgs fa{};
     fa.prof = &c->prof;
-    fa.H = H; fa.W = W; fa.T = T; fa.rgb_only = cfg->rgb_only;
+    fa.H = H; fa.W = W; fa.tiles_x = tiles_x; fa.T = T; fa.rgb_only = cfg->rgb_only;
     fa.tile_start = ba.tile_start; fa.tile_end = ba.tile_end; fa.vals_sorted = f->vals_sorted;
     fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
@@ -425,6 +427,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.prof = &c->prof;
     a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = K;
     a.H = f->info.camera_height; a.W = f->info.camera_width; a.T = f->info.n_tiles;
+    a.tiles_x = (a.W + GS_TILE - 1) / GS_TILE;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.vals_sorted = f->vals_sorted;
     a.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)f->info.n_tiles; a.tile_order = B.tile_order.as<int32_t>();
     a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();

@@ -170,7 +170,7 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
 
 struct GsBinArgs {
     GsProf* prof;
-    int64_t N; int M; uint32_t K; int H, W; float depth_scale; int depth_bits; int key_bits;
+    int64_t N; int M; uint32_t K; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
     const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
     void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64
@@ -186,7 +186,7 @@ size_t gs_scan_tmp_elems(size_t n);
 
 struct GsBlendFwdArgs {
     GsProf* prof;
-    int H, W, T; int rgb_only;
+    int H, W, tiles_x, T; int rgb_only;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
@@ -196,7 +196,7 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
 
 struct GsBackwardArgs {
     GsProf* prof;
-    int64_t N; int M; uint32_t K; int H, W, T;
+    int64_t N; int M; uint32_t K; int H, W, tiles_x, T;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const int32_t* tile_work; int32_t* tile_order;   // scheduling: heaviest tiles first
     const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                                                        const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
                                                        const uint32_t* __restrict__ offsets,
                                                        const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
-                                                       const int32_t* __restrict__ last_in, int W, int tiles_x,
+                                                       const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
                                                        float* __restrict__ partial, uint8_t* __restrict__ visited, float* __restrict__ mag_image)
 {
     __shared__ float4 sRec[64][3];             // the batch's splat records
@@ -100,8 +100,10 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     for (int qi = 0; qi < NQ; ++qi) {
         const int q = grp * NQ + qi;
         const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
-        const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
-        Q[qi].last = last_in[o];                                     // RAST:558
+        // pixels of a partial edge tile outside the image do not exist: nothing is in range for them
+        const bool inside = pu < W && pv < H;
+        const size_t o = inside ? (size_t)pv * (size_t)W + (size_t)pu : 0;
+        Q[qi].last = inside ? last_in[o] : start;                    // RAST:558
         Q[qi].T = 1.0f - acc_alpha[o];                               // RAST:559-560
         Q[qi].w0 = Q[qi].w1 = Q[qi].w2 = 0.0f;
         Q[qi].gr = grad_image[3 * o]; Q[qi].gg = grad_image[3 * o + 1]; Q[qi].gb = grad_image[3 * o + 2];
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
         for (int qi = 0; qi < NQ; ++qi) {
             const int q = grp * NQ + qi;
             const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
+            if (pu >= W || pv >= H) continue;
             const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
             mag_image[2 * o] = Q[qi].tot0; mag_image[2 * o + 1] = Q[qi].tot1;
         }
@@ -492,13 +495,13 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
         GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order));
         if (a.G == 1)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
         else if (a.G == 2)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
         else
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.W / GS_TILE_SZ, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);

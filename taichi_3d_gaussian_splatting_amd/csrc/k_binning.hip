@@ -299,7 +299,7 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     *a.vals_sorted = a.vals_a;
     if (a.N == 0 || a.M == 0) return;
     GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<(a.M + 255) / 256, 256, 0, s>>>(
-        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.W / GS_TILE_SZ, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
+        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
     if (a.K == 0) return;
     int nb, tpb;
     sort_geometry(a.K, &nb, &tpb);

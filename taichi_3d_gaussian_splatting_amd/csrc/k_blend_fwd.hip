@@ -19,7 +19,7 @@ template <bool RGB_ONLY>
 __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                    const int32_t* __restrict__ sorted_vals,
                                                    const float4* __restrict__ PA, const float4* __restrict__ PB,
-                                                   const float4* __restrict__ PC, int W, int tiles_x,
+                                                   const float4* __restrict__ PC, int W, int H, int tiles_x,
                                                    float* __restrict__ image, float* __restrict__ depth_out,
                                                    float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
                                                    int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work)
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
 
     float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, acc_d = 0.0f, norm = 0.0f;
     int last = start, count = 0;
-    bool saturated = false;
+    // a pixel of a partial edge tile that lies outside the image does not exist (extension; W,H % 16 == 0 in the reference)
+    const bool inside = pixel_u < W && pixel_v < H;
+    bool saturated = !inside;
 
     for (int base = start; base < end; base += 64) {
         if (__ballot(!saturated) == 0ull) break;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (!inside) return;
     const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
     image[3 * o] = cr; image[3 * o + 1] = cg; image[3 * o + 2] = cb;
     if (!RGB_ONLY) {
@@ -94,9 +97,9 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
     if (a.rgb_only)
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
-                                                                             a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+                                                                             a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
     else
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W,
-                                                                              a.W / GS_TILE_SZ, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
 }

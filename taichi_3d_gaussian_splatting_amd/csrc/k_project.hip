@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         float radii = sqrtf(large_eigen) * 3.0f;
         // ---- tile box + count, RAST:81-128 ----
         int box[4];
-        gs_tile_box(uv[0], uv[1], radii, W / GS_TILE_SZ, H / GS_TILE_SZ, box);
+        gs_tile_box(uv[0], uv[1], radii, (W + GS_TILE_SZ - 1) / GS_TILE_SZ, (H + GS_TILE_SZ - 1) / GS_TILE_SZ, box);   // = W/16, H/16 at the reference's sizes
         count = (box[1] - box[0]) * (box[3] - box[2]);
         depth_code = (int)(pcam[2] * depth_scale);                            // RAST:159-160
         // Conservative log-domain cut for the blend kernels: alpha = exp(e)*rescale*opacity < 1/255

@@ -22,10 +22,14 @@ def P():
 
 def _fwd_bwd(P, scene, q, t, band=3, hook=True, cfg_kw=None, seed=0):
     got = {}
-    cfg = P.Rast.GaussianPointCloudRasterisationConfig(**(cfg_kw or {}))
+    cfg_kw = dict(cfg_kw or {})
+    partial = cfg_kw.pop("allow_partial_tiles", False)
+    cfg = P.Rast.GaussianPointCloudRasterisationConfig(**cfg_kw)
+    cfg.allow_partial_tiles = partial                  # class attribute, like the grad factors (RAST:782-786)
+    cfg_kw["allow_partial_tiles"] = partial
     module = P.Rast(cfg, backward_valid_point_hook=(lambda x: got.setdefault("hook", x)) if hook else None)
     inp = P.make_input(scene, q, t, band)
-    ocfg = oracle.default_config(**{k: (int(v) if isinstance(v, bool) else v) for k, v in (cfg_kw or {}).items()})
+    ocfg = oracle.default_config(**{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg_kw.items()})
     f, feat_after = P.run_oracle(scene, q, t, ocfg)
     outs = module(inp)
     P.assert_forward_parity(module, inp, outs, f, feat_after)
@@ -347,3 +351,49 @@ def test_heavy_tile_lists_and_clustered_scene(P):
     module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=5)
     lens = f.tile_points_end - f.tile_points_start
     assert lens.max() > 1500 and f.num_overlap_tiles.max() > 500
+
+
+@pytest.mark.parametrize("n,width,height,sigma0", [(4000, 250, 203, 0.08), (300, 17, 15, 0.3), (20000, 641, 33, 0.05),
+                                                   (1500, 100, 1, 0.1)])
+def test_partial_edge_tiles_extension(P, n, width, height, sigma0):
+    """Extension: image sizes that are not multiples of 16.  Tile counts round up and the
+    pixels of an edge tile that fall outside the image do not exist; everything else is the reference's
+    algorithm, so the same bars hold against the oracle run with the same switch."""
+    s = synth(n, width, height, sigma0, seed=width)
+    q, t = view_pose()
+    module, inp, f, b, got = _fwd_bwd(P, s, q, t, cfg_kw={"allow_partial_tiles": True})
+    assert f.arrays["tile_points_start"].shape[0] == ((width + 15) // 16) * ((height + 15) // 16)
+    assert f.K > 0 and got["hook"].magnitude_grad_viewspace_on_image.shape == (height, width, 2)
+
+
+def test_partial_tiles_true_1080p_at_the_headline_density(P):
+    """5e5 Gaussians at a true 1920x1080 frame (68 tile rows, the last one half outside the image)."""
+    c = dict(CONFIGS["cfg3_headline"]); c["H"] = 1080
+    s = synth(**c)
+    q, t = view_pose()
+    module, inp, f, b, got = _fwd_bwd(P, s, q, t, cfg_kw={"allow_partial_tiles": True})
+    assert f.H == 1080 and f.arrays["tile_points_start"].shape[0] == 120 * 68
+
+
+def test_partial_tiles_switch_off_is_the_reference_contract(P):
+    """Without the switch the C ABI rejects such a size itself (error -1), as RAST:1193-1194 asserts."""
+    from taichi_3d_gaussian_splatting_amd import _native
+    s = synth(64, 40, 40, 0.2)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t, requires_grad=False)
+    with pytest.raises(AssertionError):
+        module(inp)
+    L = _native.lib()
+    import ctypes as C
+    ctx = _native.shared_ctx(0)
+    cfg = module._c_config()
+    scene = module._c_scene(inp.point_cloud, inp.point_cloud_features, inp.point_invalid_mask, inp.point_object_id)
+    out = torch.empty(5, 40, 40, 3, device=P.DEV)
+    cam = _native.GsCamera(inp.q_pointcloud_camera.data_ptr(), inp.t_pointcloud_camera.data_ptr(), 1,
+                           inp.camera_info.camera_intrinsics.data_ptr(), 40, 40)
+    fo = _native.GsForwardOut(*[out[i].data_ptr() for i in range(5)])
+    frame = C.c_void_p()
+    rc = L.gs_forward(ctx, C.byref(scene), C.byref(cam), C.byref(cfg), C.byref(fo), 0, C.byref(frame),
+                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -1 and b"multiples of 16" in L.gs_last_error()

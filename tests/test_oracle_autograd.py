@@ -10,21 +10,25 @@ from oracle import oracle
 from taichi_3d_gaussian_splatting_amd.synthetic import synth
 
 
-def _tiny(seed, n, sigma0, size=32):
-    s = synth(n, size, size, sigma0, sh_deg=3, seed=seed)
+def _tiny(seed, n, sigma0, size=32, height=None):
+    height = size if height is None else height
+    s = synth(n, size, height, sigma0, sh_deg=3, seed=seed)
     rng = np.random.default_rng(seed + 100)
     ang = 0.05
     q = np.array([[0.02, np.sin(ang / 2), -0.01, np.cos(ang / 2)]], np.float32)   # deliberately not unit
     t = np.array([[0.03, -0.02, 0.1]], np.float32)
-    target = rng.uniform(0, 1, (size, size, 3)).astype(np.float32)
+    target = rng.uniform(0, 1, (height, size, 3)).astype(np.float32)
     return s, q, t, target
 
 
-@pytest.mark.parametrize("seed,n,sigma0", [(0, 48, 0.25), (1, 64, 0.6), (2, 24, 1.2)])
-def test_backward_matches_autograd(seed, n, sigma0):
-    s, q, t, target = _tiny(seed, n, sigma0)
+@pytest.mark.parametrize("seed,n,sigma0,width,height", [(0, 48, 0.25, 32, 32), (1, 64, 0.6, 32, 32), (2, 24, 1.2, 32, 32),
+                                                         (3, 56, 0.5, 41, 27)])
+def test_backward_matches_autograd(seed, n, sigma0, width, height):
+    """The last case is the partial-tile extension (41x27: neither side a multiple of 16)."""
+    s, q, t, target = _tiny(seed, n, sigma0, width, height)
+    partial = int(width % 16 != 0 or height % 16 != 0)
     cfg = oracle.default_config(grad_color_factor=1.0, grad_high_order_color_factor=1.0, grad_s_factor=1.0,
-                                grad_q_factor=1.0, grad_alpha_factor=1.0)
+                                grad_q_factor=1.0, grad_alpha_factor=1.0, allow_partial_tiles=partial)
     f, feat_after = oracle.forward(s.point_cloud, s.point_cloud_features, s.point_invalid_mask,
                                    s.point_object_id, q, t, s.camera_intrinsics, s.height, s.width, cfg)
     assert f.K > 0 and f.pixel_valid_point_count.max() >= 3

@@ -95,10 +95,10 @@ def render(point_cloud, features, q_pc, t_pc, Kmat, H, W, fwd, object_id=None):
     color = torch.sigmoid(torch.stack([(f[:, 8:24] * Y).sum(-1), (f[:, 24:40] * Y).sum(-1), (f[:, 40:56] * Y).sum(-1)], -1))
 
     image = torch.zeros(H, W, 3, dtype=F64)
-    tiles_x = W // 16
+    tiles_x = (W + 15) // 16                       # = W // 16 at the reference's sizes; partial edge tiles are an extension
     lst = fwd.point_offset_with_sort_key
     yy, xx = torch.meshgrid(torch.arange(16, dtype=F64), torch.arange(16, dtype=F64), indexing="ij")
-    for tile in range(tiles_x * (H // 16)):
+    for tile in range(tiles_x * ((H + 15) // 16)):
         s, e = int(fwd.tile_points_start[tile]), int(fwd.tile_points_end[tile])
         if e <= s:
             continue
@@ -122,5 +122,6 @@ def render(point_cloud, features, q_pc, t_pc, Kmat, H, W, fwd, object_id=None):
             w = torch.where(use, a_c * T, torch.zeros_like(T))
             C = C + w[:, None] * color[p][None, :]
             T = torch.where(use, nT, T)
-        image[tv * 16:(tv + 1) * 16, tu * 16:(tu + 1) * 16, :] = C.reshape(16, 16, 3)
+        hh, ww = min(16, H - tv * 16), min(16, W - tu * 16)
+        image[tv * 16:tv * 16 + hh, tu * 16:tu * 16 + ww, :] = C.reshape(16, 16, 3)[:hh, :ww]
     return image, {"uv": uv, "color": color, "opacity": opacity, "cov": cov}
