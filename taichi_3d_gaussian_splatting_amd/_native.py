@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsrast.so")
+# GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
+LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
 ABI_VERSION = 3
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p

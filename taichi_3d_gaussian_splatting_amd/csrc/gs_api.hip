@@ -522,3 +522,18 @@ extern "C" int gs_frame_release(gs_ctx* c, gs_frame* f)
     drop_frame(c, f);
     return GS_OK;
 }
+
+// ---- diagnostic build only (make stats): counters of the blend kernels, tools/blend_stats.py ----
+#ifdef GS_STATS
+__device__ unsigned long long gs_stats_counters[32];
+extern "C" int gs_debug_stats_read(unsigned long long* out32, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(gs_stats_counters), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gs_stats_counters), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif

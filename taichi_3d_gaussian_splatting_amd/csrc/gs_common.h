@@ -10,6 +10,18 @@
 #include <stdint.h>
 
 #define GS_TILE_SZ 16
+
+// Wave-wide vote.  The intrinsic folds into the v_cmp that produced the predicate (an SGPR-pair mask); HIP's __ballot()
+// goes through v_cndmask + v_cmp_ne, two half-rate VALU instructions per vote.
+#define gs_ballot(pred) __builtin_amdgcn_ballot_w64(pred)
+
+// Diagnostic build only (`make stats` -> libgsrast_stats.so, tools/blend_stats.py): event counters of the two blend kernels.
+#ifdef GS_STATS
+extern __device__ unsigned long long gs_stats_counters[32];
+#define GS_STAT(i, n) do { const unsigned long long gs_stat_n = (unsigned long long)(n); if (threadIdx.x % 64 == 0) atomicAdd(&gs_stats_counters[i], gs_stat_n); } while (0)
+#else
+#define GS_STAT(i, n) do { } while (0)
+#endif
 #define GS_BOUNDARY_TILES 3          // reference RAST:26
 #define GS_ALPHA_EPS 0.00392156862745098f   // 1./255. (RAST:451, RAST:634)
 #define GS_ALPHA_MAX 0.99f           // RAST:453

@@ -130,9 +130,10 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
             unsigned long long U = 0ull;
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
-                mq[qi] = __ballot(valid && i < qlast[qi] && !gs_cull(cs, rx0[qi], ry0[qi]));
+                mq[qi] = gs_ballot(valid && i < qlast[qi] && !gs_cull(cs, rx0[qi], ry0[qi]));
                 U |= mq[qi];
             }
+            GS_STAT(8, 1);
             if (U) {
                 uint32_t slot = 0;
                 if ((U >> lane) & 1ull) {                                     // pre-sort slot of this (point, tile) pair
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                 while (U) {
                     const int j = 63 - __builtin_clzll(U);                    // back to front, RAST:605-608
                     U &= ~(1ull << j);
+                    GS_STAT(9, 1);
                     const float4 a4 = sRec[j][0], b4 = sRec[j][1], c4 = sRec[j][2];
                     const float a = a4.z, b = a4.w, c = b4.x, apt = b4.z;
                     float v[11];
@@ -153,24 +155,29 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi) {
                         if (!((mq[qi] >> j) & 1ull)) continue;                // wave-uniform
+                        GS_STAT(10, 1);
                         const int q = grp * NQ + qi;
                         // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
                         const float dx = (px_lo + (float)((q & 1) * 8)) - a4.x, dy = (py_lo + (float)((q >> 1) * 8)) - a4.y;
                         const float cix = a * dx + b * dy, ciy = b * dx + c * dy;
                         const float exponent = -0.5f * (dx * cix + dy * ciy);
-                        const bool in_range = (lo + j) < Q[qi].last;              // RAST:609-610
-                        if (__ballot(in_range && !(exponent + 0.02f < c4.w)) == 0ull) continue;
+                        // lane predicates as wave-uniform SGPR masks (see k_blend_fwd)
+                        const unsigned long long inr_m = gs_ballot((lo + j) < Q[qi].last);   // RAST:609-610
+                        if ((gs_ballot(!(exponent + 0.02f < c4.w)) & inr_m) == 0ull) continue;
+                        GS_STAT(11, 1);
                         // exp: the hardware v_exp_f32 (1 ulp) unless some lane sits within 1e-5 (relative) of the
                         // 1/255 threshold, where the reference polynomial decides (same decisions as the oracle)
                         float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
                         float prod_alpha = g * apt;
-                        if (__ballot(in_range && fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) != 0ull) {
+                        if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
                             g = gs_expf(exponent) * b4.y;
                             prod_alpha = g * apt;
+                            GS_STAT(14, 1);
                         }
-                        const bool use = in_range && prod_alpha >= GS_ALPHA_EPS; // RAST:634
-                        any_use = any_use || (__ballot(use) != 0ull);
-                        if (use) {                                               // exec-masked: idle lanes add nothing
+                        const unsigned long long use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;   // RAST:634
+                        any_use = any_use || (use_m != 0ull);
+                        GS_STAT(12, __popcll(use_m)); GS_STAT(15, use_m != 0ull ? 1 : 0);
+                        if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing
                             // float outputs only from here on: let the compiler fuse multiply-adds
 #pragma clang fp contract(fast)
                             const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         }
                     }
                     if (!any_use) continue;
+                    GS_STAT(13, 1);
                     // Sum the eleven values over the 64 lanes through a wave-private LDS transpose: 11 conflict-free
                     // ds_write_b32, then lane 4k+s adds 16 floats of value k (4 ds_read_b128, row stride 68 floats
                     // keeps the reads conflict-free) and two quad DPP adds fold s.  About 30 VALU issue slots
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
         sums[3 * (size_t)m] = s0; sums[3 * (size_t)m + 1] = s1; sums[3 * (size_t)m + 2] = s2;
     }
     // wave-cooperative pass over the large points of this wave
-    unsigned long long big = __ballot(valid && cnt > SUM_ROWS_SMALL);
+    unsigned long long big = gs_ballot(valid && cnt > SUM_ROWS_SMALL);
     while (big) {
         const int j = __builtin_ctzll(big);
         big &= big - 1ull;

@@ -38,16 +38,19 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
     int last = start, count = 0;
     // a pixel of a partial edge tile that lies outside the image does not exist (extension; W,H % 16 == 0 in the reference)
     const bool inside = pixel_u < W && pixel_v < H;
-    bool saturated = !inside;
+    // Lane predicates live as wave-uniform 64-bit masks in SGPRs (votes fold into the v_cmp that made them, and
+    // inverse_ballot turns a mask back into exec without VALU work): `alive` = lanes that have not saturated yet.
+    unsigned long long alive = gs_ballot(inside);
 
     for (int base = start; base < end; base += 64) {
-        if (__ballot(!saturated) == 0ull) break;
+        if (alive == 0ull) break;
         const int i = base + lane;
         const bool valid = i < end;
         const int p = valid ? sorted_vals[i] : 0;
         float4 A = PA[p], B = PB[p], C = PC[p];
         bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), rx0, ry0);
-        unsigned long long mask = __ballot(keep);
+        unsigned long long mask = gs_ballot(keep);
+        GS_STAT(0, 1); GS_STAT(1, __popcll(mask));
         if (mask == 0ull) continue;
         sRec[wave][lane][0] = A; sRec[wave][lane][1] = B; sRec[wave][lane][2] = C;
         __builtin_amdgcn_wave_barrier();
@@ -59,23 +62,25 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
             float dx = px - a4.x, dy = py - a4.y;
             float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
             // cheap wave-level reject before the polynomial: exp(e)*rescale*opacity < 1/255 for sure
-            if (__ballot(!saturated && !(exponent + 0.02f < c4.w)) == 0ull) continue;
+            if ((gs_ballot(!(exponent + 0.02f < c4.w)) & alive) == 0ull) { GS_STAT(4, 1); continue; }
+            GS_STAT(2, 1);
             float g = gs_expf(exponent) * b4.y;
             float alpha = g * b4.z;
-            bool use = !saturated && !(alpha < GS_ALPHA_EPS);                    // RAST:451
+            unsigned long long use_m = gs_ballot(!(alpha < GS_ALPHA_EPS)) & alive;    // RAST:451
             alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                // RAST:453
             float next_T = T_i * (1.0f - alpha);                                // RAST:457
-            bool sat_now = use && next_T < GS_T_STOP;                           // RAST:458-460
-            saturated = saturated || sat_now;
-            use = use && !sat_now;
-            if (use) {
+            const unsigned long long sat_m = gs_ballot(next_T < GS_T_STOP) & use_m;   // RAST:458-460
+            alive &= ~sat_m;
+            use_m &= ~sat_m;
+            GS_STAT(3, __popcll(use_m)); GS_STAT(5, __popcll(alive));
+            if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {
                 last = base + j + 1;                                            // RAST:461
                 // same association as the reference (colour * alpha * T_i), so the image is bit-exact
                 cr += c4.x * alpha * T_i; cg += c4.y * alpha * T_i; cb += c4.z * alpha * T_i;   // RAST:462
                 if (!RGB_ONLY) { acc_d += b4.w * alpha * T_i; norm += alpha * T_i; count += 1; } // RAST:464-469
                 T_i = next_T;
             }
-            if (__ballot(sat_now) != 0ull && __ballot(!saturated) == 0ull) { mask = 0ull; }   // re-test only when a lane just saturated
+            if (alive == 0ull) mask = 0ull;
         }
         __builtin_amdgcn_wave_barrier();
     }
