@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -125,6 +125,12 @@ typedef struct gs_backward_out {
     float*   hook_grad_viewspace;               /* device (M,2)  */
     float*   hook_magnitude_grad_viewspace;     /* device (M)    */
     const gs_controller_accumulators* controller; /* host pointer to a struct of device arrays, or NULL */
+    /* the remaining four fields of BackwardValidPointHookInput (RAST:1128-1140), each nullable; written by the same
+     * kernel as the gathers above so that a hook costs no extra launches (gs_frame_export gives the same arrays): */
+    int32_t* hook_point_id_in_camera_list;      /* device (M)    */
+    int32_t* hook_num_overlap_tiles;            /* device (M)    */
+    float*   hook_point_depth;                  /* device (M)    */
+    float*   hook_point_uv_in_camera;           /* device (M,2)  */
 } gs_backward_out;
 
 /* Intermediates a frame can copy out, in the reference's layouts (saved tensors

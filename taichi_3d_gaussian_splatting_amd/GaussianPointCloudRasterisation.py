@@ -268,6 +268,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         h_feat = e(M, 56) if want_hook else None
         h_uv = e(M, 2) if want_hook else None
         h_mag = e(M) if want_hook else None
+        h_ids = e(M, dtype=torch.int32) if want_hook else None
+        h_ntiles = e(M, dtype=torch.int32) if want_hook else None
+        h_depth = e(M) if want_hook else None
+        h_puv = e(M, 2) if want_hook else None
         ctrl = None
         if self.controller_accumulators is not None:
             ca = self.controller_accumulators
@@ -278,7 +282,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 _ptr(ca.accumulated_position_gradients), _ptr(ca.accumulated_position_gradients_norm))
         out = _native.GsBackwardOut(_ptr(grad_pc), _ptr(grad_feat), _ptr(grad_uv), _ptr(mag), _ptr(mag_img), _ptr(n_aff),
                                     _ptr(h_pc), _ptr(h_feat), _ptr(h_uv), _ptr(h_mag),
-                                    C.pointer(ctrl) if ctrl is not None and N > 0 else None)
+                                    C.pointer(ctrl) if ctrl is not None and N > 0 else None,
+                                    _ptr(h_ids), _ptr(h_ntiles), _ptr(h_depth), _ptr(h_puv))
         scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -289,11 +294,11 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                                          magnitude_grad_viewspace_on_image=mag_img, num_affected_pixels=n_aff)
         if want_hook:                                                                   # RAST:1127-1142
             self._hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
-                point_id_in_camera_list=frame.export("point_id_in_camera_list"),
+                point_id_in_camera_list=h_ids,
                 grad_point_in_camera=h_pc, grad_pointfeatures_in_camera=h_feat, grad_viewspace=h_uv,
                 magnitude_grad_viewspace=h_mag, magnitude_grad_viewspace_on_image=mag_img,
-                num_overlap_tiles=frame.export("num_overlap_tiles"), num_affected_pixels=n_aff,
-                point_depth=frame.export("point_depth"), point_uv_in_camera=frame.export("point_uv")))
+                num_overlap_tiles=h_ntiles, num_affected_pixels=n_aff,
+                point_depth=h_depth, point_uv_in_camera=h_puv))
         return grad_pc, grad_feat
 
     # ------------------------------------------------------------------ nn.Module

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
 LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -55,7 +55,9 @@ class GsBackwardOut(C.Structure):
                 ("magnitude_grad_viewspace", _VP), ("magnitude_grad_viewspace_on_image", _VP),
                 ("num_affected_pixels", _VP), ("hook_grad_point_in_camera", _VP),
                 ("hook_grad_pointfeatures_in_camera", _VP), ("hook_grad_viewspace", _VP),
-                ("hook_magnitude_grad_viewspace", _VP), ("controller", C.POINTER(GsControllerAccumulators))]
+                ("hook_magnitude_grad_viewspace", _VP), ("controller", C.POINTER(GsControllerAccumulators)),
+                ("hook_point_id_in_camera_list", _VP), ("hook_num_overlap_tiles", _VP), ("hook_point_depth", _VP),
+                ("hook_point_uv_in_camera", _VP)]
 
 
 # gs_export ids (include/gs_rasterizer.h) -> (name, numpy/torch dtype name, trailing shape)

@@ -4,6 +4,8 @@
 #include "../../include/gs_rasterizer.h"
 #include "gs_common.h"
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -108,7 +110,9 @@ struct gs_ctx {
     gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
     DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums, loss_ws;
-    GsCounters* host_counters = nullptr;   // pinned
+    GsCounters* host_counters = nullptr;   // pinned, device-visible; written by k_scan_tiles_publish
+    GsCounters* host_counters_dev = nullptr;   // the device's address of it
+    int32_t ticket = 0;                    // sequence number of the last forward
 };
 
 extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -129,8 +133,11 @@ extern "C" int gs_create(int32_t device, gs_ctx** out)
     HIP_TRY(hipSetDevice(device));
     gs_ctx* c = new gs_ctx();
     c->device = device;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_counters), sizeof(GsCounters), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_counters), sizeof(GsCounters), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) { delete c; return fail(GS_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    std::memset(c->host_counters, 0, sizeof(GsCounters));
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_counters_dev), c->host_counters, 0);
+    if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
     e = c->counters.ensure(sizeof(GsCounters), &c->device_bytes);
     if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: counters"); }
     *out = c;
@@ -284,11 +291,35 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
+    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
+    pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
+    if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_project(pa, s);
     HIP_TRY_F(hipGetLastError());
-    // the one device->host sync of the frame: M, K and the depth-code range
-    HIP_TRY_F(hipMemcpyAsync(c->host_counters, c->counters.p, sizeof(GsCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY_F(hipStreamSynchronize(s));
+    // the one device->host hand-over of the frame: M, K and the depth-code range.  The last kernel writes them into
+    // pinned host memory and then the ticket; spinning on it costs a few microseconds where a copy + stream
+    // synchronisation left the GPU idle for ~30.
+    static const bool wait_on_stream = []{ const char* e = getenv("GS_COUNTERS_WAIT"); return e && std::strcmp(e, "stream") == 0; }();
+    if (N > 0 && wait_on_stream) {                   // diagnostic alternative: block in the runtime instead of spinning
+        HIP_TRY_F(hipStreamSynchronize(s));
+    } else if (N > 0) {
+        volatile GsCounters* hc = c->host_counters;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 0; hc->reserved != pa.ticket; ++spin) {
+            if ((spin & 0xfffu) == 0xfffu) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {                         // stream drained: the ticket must be there now
+                    if (hc->reserved != pa.ticket) { drop_frame(c, f); return fail(GS_ERR_HIP, "gs_forward: frame counters were not published"); }
+                    break;
+                }
+                if (q != hipErrorNotReady) { drop_frame(c, f); return fail(GS_ERR_HIP, std::string("gs_forward: ") + hipGetErrorString(q)); }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                    drop_frame(c, f); return fail(GS_ERR_HIP, "gs_forward: timed out waiting for the frame counters");
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     const int M = N > 0 ? c->host_counters->M : 0;
     const uint32_t K = N > 0 ? c->host_counters->K : 0u;
     const int max_code = N > 0 ? c->host_counters->max_depth_code : 0;
@@ -449,6 +480,8 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.n_affected = out->num_affected_pixels;
     a.hook_gpc = out->hook_grad_point_in_camera; a.hook_gfeat = out->hook_grad_pointfeatures_in_camera;
     a.hook_guv = out->hook_grad_viewspace; a.hook_mag = out->hook_magnitude_grad_viewspace;
+    a.hook_ids = out->hook_point_id_in_camera_list; a.hook_ntiles = out->hook_num_overlap_tiles;
+    a.hook_depth = out->hook_point_depth; a.hook_uv = out->hook_point_uv_in_camera;
     if (const gs_controller_accumulators* ca = out->controller) {
         if (!ca->accumulated_num_in_camera || !ca->accumulated_num_pixels || !ca->accumulated_view_space_position_gradients ||
             !ca->accumulated_view_space_position_gradients_avg || !ca->accumulated_position_gradients || !ca->accumulated_position_gradients_norm)

@@ -177,6 +177,8 @@ struct GsProjectArgs {
     GsPose* pose; int8_t* mask; int32_t* block_counts; int32_t* block_offsets; int32_t* ids; int32_t* cam_index;
     float4 *PA, *PB, *PC, *PD; ushort4* box; int32_t* ntiles; uint32_t* tile_block_sums; uint32_t* tile_block_offsets;
     GsCounters* counters;
+    int32_t* tile_arrays; int tile_ints;        // tile_start | tile_end | tile_work, cleared before the binning
+    GsCounters* host_mirror; int32_t ticket;    // pinned host copy of the counters; .reserved = ticket once they are valid
 };
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
 
@@ -224,6 +226,7 @@ struct GsBackwardArgs {
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
     float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;
     float* hook_gpc; float* hook_gfeat; float* hook_guv; float* hook_mag;
+    int32_t* hook_ids; int32_t* hook_ntiles; float* hook_depth; float* hook_uv;
     // adaptive-controller accumulators (CTRL:114-141), all nullable together
     int32_t* c_num_in_camera; int32_t* c_num_pixels; float* c_vs_grad; float* c_vs_grad_avg; float* c_pos_grad; float* c_pos_grad_norm;
 };

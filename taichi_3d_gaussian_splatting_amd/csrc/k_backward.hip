@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     float* __restrict__ grad_pc, float* __restrict__ grad_feat, float* __restrict__ grad_uv, float* __restrict__ mag,
     int32_t* __restrict__ n_affected,
     float* __restrict__ hook_gpc, float* __restrict__ hook_gfeat, float* __restrict__ hook_guv, float* __restrict__ hook_mag,
+    int32_t* __restrict__ hook_ids, int32_t* __restrict__ hook_ntiles, float* __restrict__ hook_depth, float* __restrict__ hook_uv,
+    const float4* __restrict__ PA, const float4* __restrict__ PB, const int32_t* __restrict__ ntiles,
     int32_t* __restrict__ c_num_in_camera, int32_t* __restrict__ c_num_pixels, float* __restrict__ c_vs_grad,
     float* __restrict__ c_vs_grad_avg, float* __restrict__ c_pos_grad, float* __restrict__ c_pos_grad_norm)
 {
@@ -484,6 +486,10 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     }
     if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
     if (hook_mag) hook_mag[m] = s[9];
+    if (hook_ids) hook_ids[m] = (int32_t)n;                         // RAST:1129, 1136-1139
+    if (hook_ntiles) hook_ntiles[m] = ntiles[m];
+    if (hook_depth) hook_depth[m] = PB[m].w;
+    if (hook_uv) { const float4 pa = PA[m]; hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
     if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
         const int32_t npix = (int32_t)(s[10] + 0.5f);
         c_num_in_camera[n] += 1;
@@ -523,5 +529,6 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
                                                                     a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,
                                                                     a.hook_gpc, a.hook_gfeat, a.hook_guv, a.hook_mag,
+                                                                    a.hook_ids, a.hook_ntiles, a.hook_depth, a.hook_uv, a.PA, a.PB, a.ntiles,
                                                                     a.c_num_in_camera, a.c_num_pixels, a.c_vs_grad, a.c_vs_grad_avg, a.c_pos_grad, a.c_pos_grad_norm));
 }

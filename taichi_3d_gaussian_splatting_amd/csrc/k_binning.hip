@@ -321,8 +321,7 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
 
 void gs_launch_binning(const GsBinArgs& a, hipStream_t s)
 {
-    // tile_start | tile_end (RAST:954-957 zero-init) | tile_work are one allocation: one clear
-    (void)hipMemsetAsync(a.tile_start, 0, sizeof(int32_t) * 3 * (size_t)a.T, s);
+    // tile_start | tile_end (RAST:954-957 zero-init) | tile_work were cleared by gs_launch_project
     if (a.key64) launch_binning_t<uint64_t>(a, s);
     else launch_binning_t<uint32_t>(a, s);
 }

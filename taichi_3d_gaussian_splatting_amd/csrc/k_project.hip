@@ -290,11 +290,56 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Last kernel before the host has to know M, K and the depth-code range: exclusive scan of the per-block tile
+// counts (as k_scan_blocks), clear of the tile_start | tile_end | tile_work arrays (RAST:954-957 zero-init), and
+// publication of the frame counters straight into pinned host memory.  The host spins on `ticket` instead of
+// waiting for a copy + stream synchronisation (tens of microseconds of GPU idle per frame).
+__global__ __launch_bounds__(1024) void k_scan_tiles_publish(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
+                                                             GsCounters* __restrict__ counters, int32_t* __restrict__ tile_arrays, int tile_ints,
+                                                             volatile GsCounters* host_mirror, int32_t ticket)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < tile_ints; i += 1024) tile_arrays[i] = 0;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+        const uint32_t carry = carry_s;
+        if (i < n) out[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t K = carry_s;
+        counters->K = K;
+        host_mirror->M = counters->M;
+        host_mirror->K = K;
+        host_mirror->max_depth_code = counters->max_depth_code;
+        __threadfence_system();
+        host_mirror->reserved = ticket;              // the host waits for this value
+        __threadfence_system();
+    }
+}
+
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
 {
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) {
         GS_TIMED(a.prof, KID_POSE, s, k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters));
+        (void)hipMemsetAsync(a.tile_arrays, 0, sizeof(int32_t) * (size_t)a.tile_ints, s);     // empty scene: nothing else clears them
         return;
     }
     GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.q_pc, a.t_pc, a.n_objects,
@@ -304,5 +349,6 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters));
-    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_blocks<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, &a.counters->K));
+    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
+                                                                              a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
 }
