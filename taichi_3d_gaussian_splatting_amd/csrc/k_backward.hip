@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
 }
 
 // ---------------------------------------------------------------------------------
+#define ROW_LDS 60
 __global__ __launch_bounds__(256) void k_bwd_points(
     int64_t N, const int32_t* __restrict__ cam_index, const float4* __restrict__ sums, const float4* __restrict__ PD,
     const float* __restrict__ pc, const float* __restrict__ feat, const int32_t* __restrict__ obj,
@@ -332,18 +333,23 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     int32_t* __restrict__ c_num_in_camera, int32_t* __restrict__ c_num_pixels, float* __restrict__ c_vs_grad,
     float* __restrict__ c_vs_grad_avg, float* __restrict__ c_pos_grad, float* __restrict__ c_pos_grad_norm)
 {
-    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int m = cam_index[n];
-    float4* gf4 = reinterpret_cast<float4*>(grad_feat + (size_t)GS_NFEAT * n);
-    if (m < 0) {                                                    // RAST:1051-1058 zero rows
-        grad_pc[3 * n] = 0.0f; grad_pc[3 * n + 1] = 0.0f; grad_pc[3 * n + 2] = 0.0f;
+    // The 56-float gradient rows leave through LDS: a lane-per-row store reaches ~3.2 TB/s, the same rows written
+    // as one contiguous 14 KB run per wave ~6.2 TB/s (tools/ubench_rows.hip).  Row stride 60 floats keeps both the
+    // lane-wise float4 staging writes and the row-wise reads spread over the banks.
+    __shared__ __attribute__((aligned(16))) float sRows[4][64 * ROW_LDS + 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = n < N;
+    const int m = valid ? cam_index[n] : -1;
+    float out[GS_NFEAT];
 #pragma unroll
-        for (int k = 0; k < GS_NFEAT / 4; ++k) gf4[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < GS_NFEAT; ++k) out[k] = 0.0f;               // RAST:1051-1058 zero rows
+    if (valid && m < 0) {
+        grad_pc[3 * n] = 0.0f; grad_pc[3 * n + 1] = 0.0f; grad_pc[3 * n + 2] = 0.0f;
         if (grad_uv) { grad_uv[2 * n] = 0.0f; grad_uv[2 * n + 1] = 0.0f; }
         if (mag) mag[n] = 0.0f;
-        return;
     }
+    if (m >= 0) {
     float s[PW];
     {
         const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
@@ -452,7 +458,6 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     sh[13] = 0.45704579946446572f * ux * (1.0f - 5.0f * uz * uz);
     sh[14] = 1.4453057213202769f * uz * (ux * ux - uy * uy);
     sh[15] = 0.59004358992664352f * ux * (-ux * ux + 3.0f * uy * uy);
-    float out[GS_NFEAT];
     out[0] = gq[0] * f_q; out[1] = gq[1] * f_q; out[2] = gq[2] * f_q; out[3] = gq[3] * f_q;      // RAST:1105-1106
     out[4] = gs_[0] * f_s; out[5] = gs_[1] * f_s; out[6] = gs_[2] * f_s;                          // RAST:1107-1108
     out[7] = s[8] * f_alpha;                                                                      // RAST:1109-1110
@@ -473,17 +478,10 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         }
     }
     grad_pc[3 * n] = gt[0]; grad_pc[3 * n + 1] = gt[1]; grad_pc[3 * n + 2] = gt[2];
-#pragma unroll
-    for (int k = 0; k < GS_NFEAT / 4; ++k) gf4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
     if (grad_uv) { grad_uv[2 * n] = guv0; grad_uv[2 * n + 1] = guv1; }
     if (mag) mag[n] = s[9];
     if (n_affected) n_affected[m] = (int32_t)(s[10] + 0.5f);
     if (hook_gpc) { hook_gpc[3 * (size_t)m] = gt[0]; hook_gpc[3 * (size_t)m + 1] = gt[1]; hook_gpc[3 * (size_t)m + 2] = gt[2]; }
-    if (hook_gfeat) {
-        float4* h4 = reinterpret_cast<float4*>(hook_gfeat + (size_t)GS_NFEAT * m);
-#pragma unroll
-        for (int k = 0; k < GS_NFEAT / 4; ++k) h4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
-    }
     if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
     if (hook_mag) hook_mag[m] = s[9];
     if (hook_ids) hook_ids[m] = (int32_t)n;                         // RAST:1129, 1136-1139
@@ -499,6 +497,36 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         c_vs_grad_avg[n] += (avg != avg) ? 0.0f : avg;
         c_pos_grad[3 * n] += gt[0]; c_pos_grad[3 * n + 1] += gt[1]; c_pos_grad[3 * n + 2] += gt[2];
         c_pos_grad_norm[n] += sqrtf(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
+    }
+    }   // m >= 0
+
+    // ---- rows out: stage, then the wave writes its 64 consecutive rows of grad_feat as one contiguous run ----
+    float* mine = sRows[wave] + lane * ROW_LDS;
+#pragma unroll
+    for (int k = 0; k < GS_NFEAT / 4; ++k)
+        *reinterpret_cast<float4*>(mine + 4 * k) = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    const unsigned long long cam_m = gs_ballot(m >= 0);
+    int* rank_to_lane = reinterpret_cast<int*>(sRows[wave] + 64 * ROW_LDS);
+    if (m >= 0) rank_to_lane[__popcll(cam_m & ((1ull << lane) - 1ull))] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t n0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int rows = (int)(N - n0 < 64 ? N - n0 : 64);               // wave-uniform; <= 0 for a wave past the end
+    if (rows > 0) {
+        float4* dst = reinterpret_cast<float4*>(grad_feat + (size_t)GS_NFEAT * n0);
+        for (int e = lane; e < rows * (GS_NFEAT / 4); e += 64) {
+            const int r = e / (GS_NFEAT / 4), c = e - r * (GS_NFEAT / 4);
+            dst[e] = *reinterpret_cast<const float4*>(sRows[wave] + r * ROW_LDS + 4 * c);
+        }
+    }
+    // the hook's gather (RAST:1131): the in-camera lanes of a wave own consecutive rows m of it
+    if (hook_gfeat && cam_m != 0ull) {
+        const int m_first = __builtin_amdgcn_readlane(m, __builtin_ctzll(cam_m));
+        const int cnt = __popcll(cam_m);
+        float4* dst = reinterpret_cast<float4*>(hook_gfeat + (size_t)GS_NFEAT * m_first);
+        for (int e = lane; e < cnt * (GS_NFEAT / 4); e += 64) {
+            const int r = e / (GS_NFEAT / 4), c = e - r * (GS_NFEAT / 4);
+            dst[e] = *reinterpret_cast<const float4*>(sRows[wave] + rank_to_lane[r] * ROW_LDS + 4 * c);
+        }
     }
 }
 
