@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
             }
     }
     // points with many tiles: the wave writes them together, 64 consecutive slots per step
-    unsigned long long big = __ballot(valid && n > KEYGEN_SMALL);
+    unsigned long long big = gs_ballot(valid && n > KEYGEN_SMALL);
     while (big) {
         const int j = __builtin_ctzll(big);
         big &= big - 1ull;
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
             const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
             const bool valid = li < tile_n;
             const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
-            unsigned long long same = __ballot(valid);
+            unsigned long long same = gs_ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
                 const bool b = (d >> bit) & 1u;
-                const unsigned long long bal = __ballot(b);
+                const unsigned long long bal = gs_ballot(b);
                 same &= b ? bal : ~bal;
             }
             const uint32_t in_round = (uint32_t)__popcll(same & lt_mask);

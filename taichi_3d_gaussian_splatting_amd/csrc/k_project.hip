@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
              uv[1] >= (float)(-GS_TILE_SZ * GS_BOUNDARY_TILES) && uv[1] < (float)(H + GS_TILE_SZ * GS_BOUNDARY_TILES);
     }
     if (i < N) mask[i] = in ? 1 : 0;
-    unsigned long long b = __ballot(in);
+    unsigned long long b = gs_ballot(in);
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[wave] = __popcll(b);
     __syncthreads();
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_compact(const int8_t* __restrict__ mask
     __shared__ int wave_pre[4];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool in = i < N && mask[i] != 0;
-    unsigned long long b = __ballot(in);
+    unsigned long long b = gs_ballot(in);
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pre = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) pre += block_counts[j];
