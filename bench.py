@@ -168,6 +168,7 @@ def main():
 
     # ---- untimed diagnostic pass: every kernel timed, to find the dominant one ----
     prof((1 << len(names)) - 1)
+    args.breakdown_steps = max(args.breakdown_steps, 1)         # the dominant kernel has to be found before the timed region
     for _ in range(args.breakdown_steps):
         step()
     sync_all()

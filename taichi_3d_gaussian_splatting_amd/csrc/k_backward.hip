@@ -350,154 +350,154 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         if (mag) mag[n] = 0.0f;
     }
     if (m >= 0) {
-    float s[PW];
-    {
-        const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
-        s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
-        s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
-    }
-    const float guv0 = s[0], guv1 = s[1];
-    const float g00 = s[2], g01 = s[3], g11 = s[4];
-    const float4* row4 = reinterpret_cast<const float4*>(feat + (size_t)GS_NFEAT * n);
-    float row[GS_NFEAT];
-#pragma unroll
-    for (int k = 0; k < GS_NFEAT / 4; ++k) {
-        float4 v = row4[k];
-        row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
-    }
-    const GsPose& P = pose[obj[n]];
-    float Km[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Km[k] = Kmat[k];
-    const float x = pc[3 * n], y = pc[3 * n + 1], z = pc[3 * n + 2];
-    // ---- d uv / d xyz, GP3D:132-159 ----
-    float tx = ((P.R[0] * x + P.R[1] * y) + P.R[2] * z) + P.t[0];
-    float ty = ((P.R[3] * x + P.R[4] * y) + P.R[5] * z) + P.t[1];
-    float tz = ((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2];
-    float d[6] = { Km[0] / tz, Km[1] / tz, (-Km[0] * tx - Km[1] * ty) / (tz * tz),
-                   Km[3] / tz, Km[4] / tz, (-Km[3] * tx - Km[4] * ty) / (tz * tz) };
-    float gcam[3] = { guv0 * d[0] + guv1 * d[3], guv0 * d[1] + guv1 * d[4], guv0 * d[2] + guv1 * d[5] };
-    float gt[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) gt[j] = gcam[0] * P.R[j] + gcam[1] * P.R[3 + j] + gcam[2] * P.R[6 + j];   // RAST:757
-    // ---- d Sigma' / d(q, s), GP3D:237-331, contracted with (g00 g01; g01 g11) ----
-    const float4 pd = PD[m];                                        // translation_camera, RAST:737-738
-    const float fx = Km[0], fy = Km[4];
-    float J[6] = { fx / pd.z, 0.0f, -(fx * pd.x) / (pd.z * pd.z), 0.0f, fy / pd.z, -(fy * pd.y) / (pd.z * pd.z) };
-    float U[6];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        U[j] = J[0] * P.R[j] + J[2] * P.R[6 + j];
-        U[3 + j] = J[4] * P.R[3 + j] + J[5] * P.R[6 + j];
-    }
-    const float qx = row[0], qy = row[1], qz = row[2], qw = row[3];
-    float R[9];
-    {
-        float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
-        R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz); R[2] = 2.0f * (xz + wy);
-        R[3] = 2.0f * (xy + wz); R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
-        R[6] = 2.0f * (xz - wy); R[7] = 2.0f * (yz + wx); R[8] = 1.0f - 2.0f * (xx + yy);
-    }
-    const float es[3] = { gs_expf(row[4]), gs_expf(row[5]), gs_expf(row[6]) };
-    float Mm[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Mm[3 * i + j] = R[3 * i + j] * es[j];       // M = R S, GP3D:257
-    float UM[6];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) UM[3 * a + j] = U[3 * a] * Mm[j] + U[3 * a + 1] * Mm[3 + j] + U[3 * a + 2] * Mm[6 + j];
-    float gUM[6];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { gUM[j] = g00 * UM[j] + g01 * UM[3 + j]; gUM[3 + j] = g01 * UM[j] + g11 * UM[3 + j]; }
-    float GM[9];   // dL/dM = 2 U^T g (U M)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) GM[3 * i + j] = 2.0f * (U[i] * gUM[j] + U[3 + i] * gUM[3 + j]);
-    float gs_[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) gs_[j] = (GM[j] * R[j] + GM[3 + j] * R[3 + j] + GM[6 + j] * R[6 + j]) * es[j];   // GP3D:297-313
-    const float sx = es[0], sy = es[1], sz = es[2];
-    // dM/dq, GP3D:319-329 (rows = M entries 00 01 02 10 11 12 20 21 22; columns = q x y z w)
-    const float dMdq[36] = {
-        0.0f, -4 * sx * qy, -4 * sx * qz, 0.0f,
-        2 * sy * qy, 2 * sy * qx, -2 * sy * qw, -2 * sy * qz,
-        2 * sz * qz, 2 * sz * qw, 2 * sz * qx, 2 * sz * qy,
-        2 * sx * qy, 2 * sx * qx, 2 * sx * qw, 2 * sx * qz,
-        -4 * sy * qx, 0.0f, -4 * sy * qz, 0.0f,
-        -2 * sz * qw, 2 * sz * qz, 2 * sz * qy, -2 * sz * qx,
-        2 * sx * qz, -2 * sx * qw, 2 * sx * qx, -2 * sx * qy,
-        2 * sy * qw, 2 * sy * qz, 2 * sy * qy, 2 * sy * qx,
-        -4 * sz * qx, -4 * sz * qy, 0.0f, 0.0f };
-    float gq[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-    for (int e = 0; e < 9; ++e)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gq[k] += GM[e] * dMdq[4 * e + k];
-    // ---- colour, GP3D:351-373 with the backward's ray origin (RAST:731-732, 749) ----
-    float dx = x - P.origin_bwd[0], dy = y - P.origin_bwd[1], dz = z - P.origin_bwd[2];
-    float dn = sqrtf(dx * dx + dy * dy + dz * dz);
-    float ux = dx / dn, uy = dy / dn, uz = dz / dn;
-    float sh[16];
-    sh[0] = 0.28209479177387814f;
-    sh[1] = -0.48860251190291987f * uy;
-    sh[2] = 0.48860251190291987f * uz;
-    sh[3] = -0.48860251190291987f * ux;
-    sh[4] = 1.0925484305920792f * ux * uy;
-    sh[5] = -1.0925484305920792f * uy * uz;
-    sh[6] = 0.94617469575755997f * uz * uz - 0.31539156525251999f;
-    sh[7] = -1.0925484305920792f * ux * uz;
-    sh[8] = 0.54627421529603959f * ux * ux - 0.54627421529603959f * uy * uy;
-    sh[9] = 0.59004358992664352f * uy * (-3.0f * ux * ux + uy * uy);
-    sh[10] = 2.8906114426405538f * ux * uy * uz;
-    sh[11] = 0.45704579946446572f * uy * (1.0f - 5.0f * uz * uz);
-    sh[12] = 0.3731763325901154f * uz * (5.0f * uz * uz - 3.0f);
-    sh[13] = 0.45704579946446572f * ux * (1.0f - 5.0f * uz * uz);
-    sh[14] = 1.4453057213202769f * uz * (ux * ux - uy * uy);
-    sh[15] = 0.59004358992664352f * ux * (-ux * ux + 3.0f * uy * uy);
-    out[0] = gq[0] * f_q; out[1] = gq[1] * f_q; out[2] = gq[2] * f_q; out[3] = gq[3] * f_q;      // RAST:1105-1106
-    out[4] = gs_[0] * f_s; out[5] = gs_[1] * f_s; out[6] = gs_[2] * f_s;                          // RAST:1107-1108
-    out[7] = s[8] * f_alpha;                                                                      // RAST:1109-1110
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float* f = row + 8 + 16 * ch;
-        float accd = f[0] * sh[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) accd = accd + f[k] * sh[k];
-        float sg = gs_sigmoid(accd);
-        float jac = sg * (1.0f - sg);
-        float gc = s[5 + ch];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float v = gc * (jac * sh[k]);                           // RAST:754-756
-            v = k < keep ? v * (k == 0 ? f_color : f_high) : 0.0f;  // RAST:1167-1182, 1112-1125
-            out[8 + 16 * ch + k] = v;
+        float s[PW];
+        {
+            const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
+            s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
+            s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
         }
-    }
-    grad_pc[3 * n] = gt[0]; grad_pc[3 * n + 1] = gt[1]; grad_pc[3 * n + 2] = gt[2];
-    if (grad_uv) { grad_uv[2 * n] = guv0; grad_uv[2 * n + 1] = guv1; }
-    if (mag) mag[n] = s[9];
-    if (n_affected) n_affected[m] = (int32_t)(s[10] + 0.5f);
-    if (hook_gpc) { hook_gpc[3 * (size_t)m] = gt[0]; hook_gpc[3 * (size_t)m + 1] = gt[1]; hook_gpc[3 * (size_t)m + 2] = gt[2]; }
-    if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
-    if (hook_mag) hook_mag[m] = s[9];
-    if (hook_ids) hook_ids[m] = (int32_t)n;                         // RAST:1129, 1136-1139
-    if (hook_ntiles) hook_ntiles[m] = ntiles[m];
-    if (hook_depth) hook_depth[m] = PB[m].w;
-    if (hook_uv) { const float4 pa = PA[m]; hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
-    if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
-        const int32_t npix = (int32_t)(s[10] + 0.5f);
-        c_num_in_camera[n] += 1;
-        c_num_pixels[n] += npix;
-        c_vs_grad[n] += s[9];
-        const float avg = s[9] / (float)npix;                       // 0/0 -> NaN -> 0 (CTRL:138-139); x/0 -> inf is kept
-        c_vs_grad_avg[n] += (avg != avg) ? 0.0f : avg;
-        c_pos_grad[3 * n] += gt[0]; c_pos_grad[3 * n + 1] += gt[1]; c_pos_grad[3 * n + 2] += gt[2];
-        c_pos_grad_norm[n] += sqrtf(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
-    }
+        const float guv0 = s[0], guv1 = s[1];
+        const float g00 = s[2], g01 = s[3], g11 = s[4];
+        const float4* row4 = reinterpret_cast<const float4*>(feat + (size_t)GS_NFEAT * n);
+        float row[GS_NFEAT];
+#pragma unroll
+        for (int k = 0; k < GS_NFEAT / 4; ++k) {
+            float4 v = row4[k];
+            row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+        }
+        const GsPose& P = pose[obj[n]];
+        float Km[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Km[k] = Kmat[k];
+        const float x = pc[3 * n], y = pc[3 * n + 1], z = pc[3 * n + 2];
+        // ---- d uv / d xyz, GP3D:132-159 ----
+        float tx = ((P.R[0] * x + P.R[1] * y) + P.R[2] * z) + P.t[0];
+        float ty = ((P.R[3] * x + P.R[4] * y) + P.R[5] * z) + P.t[1];
+        float tz = ((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2];
+        float d[6] = { Km[0] / tz, Km[1] / tz, (-Km[0] * tx - Km[1] * ty) / (tz * tz),
+                       Km[3] / tz, Km[4] / tz, (-Km[3] * tx - Km[4] * ty) / (tz * tz) };
+        float gcam[3] = { guv0 * d[0] + guv1 * d[3], guv0 * d[1] + guv1 * d[4], guv0 * d[2] + guv1 * d[5] };
+        float gt[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gt[j] = gcam[0] * P.R[j] + gcam[1] * P.R[3 + j] + gcam[2] * P.R[6 + j];   // RAST:757
+        // ---- d Sigma' / d(q, s), GP3D:237-331, contracted with (g00 g01; g01 g11) ----
+        const float4 pd = PD[m];                                        // translation_camera, RAST:737-738
+        const float fx = Km[0], fy = Km[4];
+        float J[6] = { fx / pd.z, 0.0f, -(fx * pd.x) / (pd.z * pd.z), 0.0f, fy / pd.z, -(fy * pd.y) / (pd.z * pd.z) };
+        float U[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            U[j] = J[0] * P.R[j] + J[2] * P.R[6 + j];
+            U[3 + j] = J[4] * P.R[3 + j] + J[5] * P.R[6 + j];
+        }
+        const float qx = row[0], qy = row[1], qz = row[2], qw = row[3];
+        float R[9];
+        {
+            float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+            R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz); R[2] = 2.0f * (xz + wy);
+            R[3] = 2.0f * (xy + wz); R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
+            R[6] = 2.0f * (xz - wy); R[7] = 2.0f * (yz + wx); R[8] = 1.0f - 2.0f * (xx + yy);
+        }
+        const float es[3] = { gs_expf(row[4]), gs_expf(row[5]), gs_expf(row[6]) };
+        float Mm[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Mm[3 * i + j] = R[3 * i + j] * es[j];       // M = R S, GP3D:257
+        float UM[6];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) UM[3 * a + j] = U[3 * a] * Mm[j] + U[3 * a + 1] * Mm[3 + j] + U[3 * a + 2] * Mm[6 + j];
+        float gUM[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { gUM[j] = g00 * UM[j] + g01 * UM[3 + j]; gUM[3 + j] = g01 * UM[j] + g11 * UM[3 + j]; }
+        float GM[9];   // dL/dM = 2 U^T g (U M)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GM[3 * i + j] = 2.0f * (U[i] * gUM[j] + U[3 + i] * gUM[3 + j]);
+        float gs_[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gs_[j] = (GM[j] * R[j] + GM[3 + j] * R[3 + j] + GM[6 + j] * R[6 + j]) * es[j];   // GP3D:297-313
+        const float sx = es[0], sy = es[1], sz = es[2];
+        // dM/dq, GP3D:319-329 (rows = M entries 00 01 02 10 11 12 20 21 22; columns = q x y z w)
+        const float dMdq[36] = {
+            0.0f, -4 * sx * qy, -4 * sx * qz, 0.0f,
+            2 * sy * qy, 2 * sy * qx, -2 * sy * qw, -2 * sy * qz,
+            2 * sz * qz, 2 * sz * qw, 2 * sz * qx, 2 * sz * qy,
+            2 * sx * qy, 2 * sx * qx, 2 * sx * qw, 2 * sx * qz,
+            -4 * sy * qx, 0.0f, -4 * sy * qz, 0.0f,
+            -2 * sz * qw, 2 * sz * qz, 2 * sz * qy, -2 * sz * qx,
+            2 * sx * qz, -2 * sx * qw, 2 * sx * qx, -2 * sx * qy,
+            2 * sy * qw, 2 * sy * qz, 2 * sy * qy, 2 * sy * qx,
+            -4 * sz * qx, -4 * sz * qy, 0.0f, 0.0f };
+        float gq[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gq[k] += GM[e] * dMdq[4 * e + k];
+        // ---- colour, GP3D:351-373 with the backward's ray origin (RAST:731-732, 749) ----
+        float dx = x - P.origin_bwd[0], dy = y - P.origin_bwd[1], dz = z - P.origin_bwd[2];
+        float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+        float ux = dx / dn, uy = dy / dn, uz = dz / dn;
+        float sh[16];
+        sh[0] = 0.28209479177387814f;
+        sh[1] = -0.48860251190291987f * uy;
+        sh[2] = 0.48860251190291987f * uz;
+        sh[3] = -0.48860251190291987f * ux;
+        sh[4] = 1.0925484305920792f * ux * uy;
+        sh[5] = -1.0925484305920792f * uy * uz;
+        sh[6] = 0.94617469575755997f * uz * uz - 0.31539156525251999f;
+        sh[7] = -1.0925484305920792f * ux * uz;
+        sh[8] = 0.54627421529603959f * ux * ux - 0.54627421529603959f * uy * uy;
+        sh[9] = 0.59004358992664352f * uy * (-3.0f * ux * ux + uy * uy);
+        sh[10] = 2.8906114426405538f * ux * uy * uz;
+        sh[11] = 0.45704579946446572f * uy * (1.0f - 5.0f * uz * uz);
+        sh[12] = 0.3731763325901154f * uz * (5.0f * uz * uz - 3.0f);
+        sh[13] = 0.45704579946446572f * ux * (1.0f - 5.0f * uz * uz);
+        sh[14] = 1.4453057213202769f * uz * (ux * ux - uy * uy);
+        sh[15] = 0.59004358992664352f * ux * (-ux * ux + 3.0f * uy * uy);
+        out[0] = gq[0] * f_q; out[1] = gq[1] * f_q; out[2] = gq[2] * f_q; out[3] = gq[3] * f_q;      // RAST:1105-1106
+        out[4] = gs_[0] * f_s; out[5] = gs_[1] * f_s; out[6] = gs_[2] * f_s;                          // RAST:1107-1108
+        out[7] = s[8] * f_alpha;                                                                      // RAST:1109-1110
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* f = row + 8 + 16 * ch;
+            float accd = f[0] * sh[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) accd = accd + f[k] * sh[k];
+            float sg = gs_sigmoid(accd);
+            float jac = sg * (1.0f - sg);
+            float gc = s[5 + ch];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float v = gc * (jac * sh[k]);                           // RAST:754-756
+                v = k < keep ? v * (k == 0 ? f_color : f_high) : 0.0f;  // RAST:1167-1182, 1112-1125
+                out[8 + 16 * ch + k] = v;
+            }
+        }
+        grad_pc[3 * n] = gt[0]; grad_pc[3 * n + 1] = gt[1]; grad_pc[3 * n + 2] = gt[2];
+        if (grad_uv) { grad_uv[2 * n] = guv0; grad_uv[2 * n + 1] = guv1; }
+        if (mag) mag[n] = s[9];
+        if (n_affected) n_affected[m] = (int32_t)(s[10] + 0.5f);
+        if (hook_gpc) { hook_gpc[3 * (size_t)m] = gt[0]; hook_gpc[3 * (size_t)m + 1] = gt[1]; hook_gpc[3 * (size_t)m + 2] = gt[2]; }
+        if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
+        if (hook_mag) hook_mag[m] = s[9];
+        if (hook_ids) hook_ids[m] = (int32_t)n;                         // RAST:1129, 1136-1139
+        if (hook_ntiles) hook_ntiles[m] = ntiles[m];
+        if (hook_depth) hook_depth[m] = PB[m].w;
+        if (hook_uv) { const float4 pa = PA[m]; hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
+        if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
+            const int32_t npix = (int32_t)(s[10] + 0.5f);
+            c_num_in_camera[n] += 1;
+            c_num_pixels[n] += npix;
+            c_vs_grad[n] += s[9];
+            const float avg = s[9] / (float)npix;                       // 0/0 -> NaN -> 0 (CTRL:138-139); x/0 -> inf is kept
+            c_vs_grad_avg[n] += (avg != avg) ? 0.0f : avg;
+            c_pos_grad[3 * n] += gt[0]; c_pos_grad[3 * n + 1] += gt[1]; c_pos_grad[3 * n + 2] += gt[2];
+            c_pos_grad_norm[n] += sqrtf(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
+        }
     }   // m >= 0
 
     // ---- rows out: stage, then the wave writes its 64 consecutive rows of grad_feat as one contiguous run ----
