@@ -249,72 +249,83 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------
-// Per-point sum of the visited rows of `partial` (fixed order => bitwise reproducible).  One lane
-// per in-camera point for points with at most 16 tiles (unconditional loads, four rows in flight;
-// unvisited rows read a shared all-zero row); a point with more tiles is summed by its whole wave
-// (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the
-// critical path of the launch.
-#define SUM_ROWS_SMALL 16
+// Per-point sum of the visited rows of `partial` (fixed order => bitwise reproducible).  FOUR lanes per
+// in-camera point: lane q of the quad takes rows q, q+4, q+8, ... so a point with at most 32 rows has all its
+// loads in flight at once (the kernel is latency bound: flag byte -> row), unvisited rows read a shared all-zero
+// row, and two quad DPP steps fold the four partial sums.  A point with more rows is summed by its whole wave
+// (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the critical path.
+#define SUM_ROWS_SMALL 32
 __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
                                                   const float* __restrict__ partial, const uint8_t* __restrict__ visited,
                                                   const float4* __restrict__ zero_row, float4* __restrict__ sums)
 {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t >> 2, q = t & 3;
     const int lane = threadIdx.x & 63;
     const bool valid = m < M;
     const uint32_t off = valid ? offsets[m] * (uint32_t)G : 0u;      // G rows per (point, tile) pair
     const int cnt = valid ? ntiles[m] * G : 0;
-    if (valid && cnt <= SUM_ROWS_SMALL) {
+    float v[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = 0.0f;
+    if (cnt <= SUM_ROWS_SMALL) {
         const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)off * PW);
         const uint8_t* vis = visited + off;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-        for (int i = 0; i < cnt; i += 4) {
-            const float4* r[4];
+        const float4* r[SUM_ROWS_SMALL / 4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool on = (i + k < cnt) && vis[i + k] != 0;
-                r[k] = on ? rows + 3 * (i + k) : zero_row;
-            }
+        for (int k = 0; k < SUM_ROWS_SMALL / 4; ++k) {
+            const int i = q + 4 * k;
+            const bool on = i < cnt && vis[i] != 0;
+            r[k] = on ? rows + 3 * i : zero_row;
+        }
+#pragma unroll
+        for (int h = 0; h < SUM_ROWS_SMALL / 4; h += 4) {
+            if (4 * h >= cnt) break;                                  // wave-divergent but cheap: most points have few rows
             float4 a[4], b[4], c[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = r[k][0]; b[k] = r[k][1]; c[k] = r[k][2]; }
+            for (int k = 0; k < 4; ++k) { a[k] = r[h + k][0]; b[k] = r[h + k][1]; c[k] = r[h + k][2]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                s0.x += a[k].x; s0.y += a[k].y; s0.z += a[k].z; s0.w += a[k].w;
-                s1.x += b[k].x; s1.y += b[k].y; s1.z += b[k].z; s1.w += b[k].w;
-                s2.x += c[k].x; s2.y += c[k].y; s2.z += c[k].z; s2.w += c[k].w;
+                v[0] += a[k].x; v[1] += a[k].y; v[2] += a[k].z; v[3] += a[k].w;
+                v[4] += b[k].x; v[5] += b[k].y; v[6] += b[k].z; v[7] += b[k].w;
+                v[8] += c[k].x; v[9] += c[k].y; v[10] += c[k].z;
             }
         }
-        sums[3 * (size_t)m] = s0; sums[3 * (size_t)m + 1] = s1; sums[3 * (size_t)m + 2] = s2;
     }
-    // wave-cooperative pass over the large points of this wave
-    unsigned long long big = gs_ballot(valid && cnt > SUM_ROWS_SMALL);
+    GS_DPP11("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    GS_DPP11("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    asm volatile("s_nop 1");
+    if (valid && q == 0 && cnt <= SUM_ROWS_SMALL) {
+        sums[3 * (size_t)m] = make_float4(v[0], v[1], v[2], v[3]);
+        sums[3 * (size_t)m + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        sums[3 * (size_t)m + 2] = make_float4(v[8], v[9], v[10], 0.0f);
+    }
+    // wave-cooperative pass over the large points of this wave (one vote per quad leader)
+    unsigned long long big = gs_ballot(valid && q == 0 && cnt > SUM_ROWS_SMALL);
     while (big) {
         const int j = __builtin_ctzll(big);
         big &= big - 1ull;
         const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
         const int bcnt = __builtin_amdgcn_readlane(cnt, j);
+        const int bm = __builtin_amdgcn_readlane(m, j);
         const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)boff * PW);
         const uint8_t* vis = visited + boff;
-        float v[11];
-        float pad = 0.0f;
+        float w[11];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) v[k] = 0.0f;
+        for (int k = 0; k < 11; ++k) w[k] = 0.0f;
         for (int i = lane; i < bcnt; i += 64) {
             if (vis[i]) {
                 const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                v[8] += c.x; v[9] += c.y; v[10] += c.z; pad += c.w;
+                w[0] += a.x; w[1] += a.y; w[2] += a.z; w[3] += a.w; w[4] += b.x; w[5] += b.y; w[6] += b.z; w[7] += b.w;
+                w[8] += c.x; w[9] += c.y; w[10] += c.z;
             }
         }
-        gs_wave_sum11_row3(v);
+        gs_wave_sum11_row3(w);
         if (lane == 63) {
-            const size_t mj = (size_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + j);
-            sums[3 * mj] = make_float4(v[0], v[1], v[2], v[3]);
-            sums[3 * mj + 1] = make_float4(v[4], v[5], v[6], v[7]);
-            sums[3 * mj + 2] = make_float4(v[8], v[9], v[10], 0.0f);
+            sums[3 * (size_t)bm] = make_float4(w[0], w[1], w[2], w[3]);
+            sums[3 * (size_t)bm + 1] = make_float4(w[4], w[5], w[6], w[7]);
+            sums[3 * (size_t)bm + 2] = make_float4(w[8], w[9], w[10], 0.0f);
         }
-        (void)pad;
     }
 }
 
@@ -551,7 +562,7 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
     if (a.M > 0)
-        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(a.M + 255) / 256, 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
                                                                                   a.zero_row, a.sums));
     GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.sums, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
