@@ -254,10 +254,11 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         Kmat = self._validate(pointcloud, features, mask, obj, q, t, camera_info)
         if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (H, W, 3):
             raise ValueError("grad of rasterized_image must be float32 (H,W,3)")
-        # one allocation for both gradients so that data-parallel training all-reduces ONE buffer
+        # one allocation for both gradients so that data-parallel training all-reduces ONE buffer; the 56-float rows
+        # come first: 224*N bytes keep them 16-byte aligned for any N (the kernels store them as float4)
         flat = torch.empty(N * 59, dtype=torch.float32, device=dev)
-        grad_pc = flat[:N * 3].view(N, 3)
-        grad_feat = flat[N * 3:].view(N, 56)
+        grad_feat = flat[:N * 56].view(N, 56)
+        grad_pc = flat[N * 56:].view(N, 3)
         want_hook = self._hook is not None
         e = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)
         grad_uv = e(N, 2) if want_hook else None

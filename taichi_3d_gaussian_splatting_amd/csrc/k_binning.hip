@@ -25,6 +25,9 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
                                                 int32_t* __restrict__ vals)
 {
     __shared__ uint32_t ws[4];
+    __shared__ KeyT sk[4][64 * KEYGEN_SMALL];        // pairs of the wave's small points: key, slot, point
+    __shared__ uint32_t ss[4][64 * KEYGEN_SMALL];
+    __shared__ int32_t sv[4][64 * KEYGEN_SMALL];
     int idx = blockIdx.x * 256 + threadIdx.x;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t n = idx < M ? (uint32_t)ntiles[idx] : 0u;
@@ -45,17 +48,29 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
         depth_code = (KeyT)(uint32_t)(int)(PB[idx].w * depth_scale);         // RAST:159-160
     }
     const int du = (int)bx.y - (int)bx.x, dv = (int)bx.w - (int)bx.z;
-    // points with few tiles: one lane writes all of its pairs
-    if (valid && n <= KEYGEN_SMALL) {
+    // points with few tiles: a lane lists its pairs in LDS, then the wave writes all of them out together so that
+    // consecutive lanes store consecutive slots (a lane-per-run store pattern touches ~64 lines per instruction)
+    const uint32_t n_small = (valid && n <= KEYGEN_SMALL) ? n : 0u;
+    uint32_t sincl = n_small;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(sincl, o, 64); if (lane >= o) sincl += t; }
+    const uint32_t wave_small = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+    if (n_small) {
+        uint32_t e = sincl - n_small;
         for (int tu = bx.x; tu < bx.y; ++tu)
             for (int tv = bx.z; tv < bx.w; ++tv) {
-                uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
-                if (slot < K_cap) {
-                    KeyT tile_id = (KeyT)(tu + tv * tiles_x);                       // RAST:167-168
-                    keys[slot] = (tile_id << depth_bits) | depth_code;
-                    vals[slot] = idx;
-                }
+                const uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
+                const KeyT tile_id = (KeyT)(tu + tv * tiles_x);                           // RAST:167-168
+                sk[wave][e] = (tile_id << depth_bits) | depth_code;
+                ss[wave][e] = slot;
+                sv[wave][e] = idx;
+                ++e;
             }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < wave_small; e += 64) {
+        const uint32_t slot = ss[wave][e];
+        if (slot < K_cap) { keys[slot] = sk[wave][e]; vals[slot] = sv[wave][e]; }
     }
     // points with many tiles: the wave writes them together, 64 consecutive slots per step
     unsigned long long big = gs_ballot(valid && n > KEYGEN_SMALL);

@@ -39,10 +39,13 @@ def views_of_rank(n_views: int, rank: int, world_size: int) -> List[int]:
 def _flat_base(grad_pc: torch.Tensor, grad_feat: torch.Tensor) -> Optional[torch.Tensor]:
     """The flat 59*N buffer if the two gradients are adjacent views of one allocation, else None."""
     n = grad_pc.shape[0]
-    if (grad_pc.dtype == grad_feat.dtype == torch.float32 and grad_pc.is_contiguous() and grad_feat.is_contiguous()
+    if not (grad_pc.dtype == grad_feat.dtype == torch.float32 and grad_pc.is_contiguous() and grad_feat.is_contiguous()
             and grad_pc.device == grad_feat.device and n == grad_feat.shape[0]
-            and grad_pc.untyped_storage().data_ptr() == grad_feat.untyped_storage().data_ptr()
-            and grad_feat.storage_offset() == grad_pc.storage_offset() + 3 * n):
+            and grad_pc.untyped_storage().data_ptr() == grad_feat.untyped_storage().data_ptr()):
+        return None
+    if grad_pc.storage_offset() == grad_feat.storage_offset() + 56 * n:       # [features | positions], the operator's layout
+        return torch.as_strided(grad_feat, (59 * n,), (1,), grad_feat.storage_offset())
+    if grad_feat.storage_offset() == grad_pc.storage_offset() + 3 * n:        # [positions | features]
         return torch.as_strided(grad_pc, (59 * n,), (1,), grad_pc.storage_offset())
     return None
 

@@ -37,7 +37,7 @@ def _worker(rank, world, port, flat_layout, out_dir):
     n = 1500
     if flat_layout:                       # the operator's layout: two views of one 59*N buffer
         flat = torch.zeros(59 * n)
-        gpc, gft = flat[:3 * n].view(n, 3), flat[3 * n:].view(n, 56)
+        gft, gpc = flat[:56 * n].view(n, 56), flat[56 * n:].view(n, 3)
     else:
         gpc, gft = torch.zeros(n, 3), torch.zeros(n, 56)
     for v in views:

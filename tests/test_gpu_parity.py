@@ -397,3 +397,13 @@ def test_partial_tiles_switch_off_is_the_reference_contract(P):
     rc = L.gs_forward(ctx, C.byref(scene), C.byref(cam), C.byref(cfg), C.byref(fo), 0, C.byref(frame),
                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -1 and b"multiples of 16" in L.gs_last_error()
+
+
+@pytest.mark.parametrize("n", [1, 3, 1001, 4099])
+def test_point_counts_that_are_not_multiples_of_four(P, n):
+    """The two gradients share one 59*N allocation; the float4-stored feature rows must stay 16-byte aligned for any N
+    (found by tools/parity_soak.py: N = 1016 + 1 failed when the positions came first in that buffer)."""
+    s = synth(n, 96, 64, 0.15, seed=n)
+    q, t = view_pose()
+    module, inp, f, b, got = _fwd_bwd(P, s, q, t)
+    assert inp.point_cloud_features.grad.data_ptr() % 16 == 0
