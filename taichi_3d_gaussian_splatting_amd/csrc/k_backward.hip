@@ -69,7 +69,9 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     }
 }
 
-struct QuadState { float T, w0, w1, w2, gr, gg, gb, tot0, tot1; int last; };
+// W = sum over the splats behind of (colour . pixel gradient) * alpha * T: the reference's three accumulated colours
+// (RAST:656) only ever enter through this dot product (RAST:653-657), so one scalar per pixel carries them.
+struct QuadState { float T, W, gr, gg, gb, tot0, tot1; int last; };
 
 // NQ = quadrants per wave: 4 (one wave per tile), 2 (two waves per tile, upper / lower half) or 1.
 // With G = 4/NQ waves per tile every (point, tile) pair owns G consecutive rows of `partial`.
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
         const size_t o = inside ? (size_t)pv * (size_t)W + (size_t)pu : 0;
         Q[qi].last = inside ? last_in[o] : start;                    // RAST:558
         Q[qi].T = 1.0f - acc_alpha[o];                               // RAST:559-560
-        Q[qi].w0 = Q[qi].w1 = Q[qi].w2 = 0.0f;
+        Q[qi].W = 0.0f;
         Q[qi].gr = grad_image[3 * o]; Q[qi].gg = grad_image[3 * o + 1]; Q[qi].gb = grad_image[3 * o + 2];
         Q[qi].tot0 = Q[qi].tot1 = 0.0f;
         qlast[qi] = gs_wave_max_i(Q[qi].last);
@@ -185,28 +187,28 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             const float inv = __builtin_amdgcn_rcpf(one_m);
                             float Tn = Q[qi].T * inv;                              // RAST:643 (rcp + one correction)
                             Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[qi].T), inv, Tn);
-                            const float ag = (c4.x * Tn - Q[qi].w0 * inv) * Q[qi].gr + (c4.y * Tn - Q[qi].w1 * inv) * Q[qi].gg +
-                                             (c4.z * Tn - Q[qi].w2 * inv) * Q[qi].gb;   // RAST:653-657
+                            // d alpha: sum_c (colour_c*T - accumulated_c/(1-alpha)) * g_c, RAST:653-657, with the sums over c taken first
+                            const float cg = c4.x * Q[qi].gr + c4.y * Q[qi].gg + c4.z * Q[qi].gb;
+                            const float ag = Tn * cg - inv * Q[qi].W;
                             const float d_rgb = alpha * Tn;                     // RAST:649
-                            const float gag = ag * apt;                         // RAST:662
-                            const float hg = 0.5f * g * gag;
-                            const float vs0 = gag * (g * cix), vs1 = gag * (g * ciy);   // RAST:664-665
+                            // Per-splat constant factors are applied once per point in k_bwd_points instead of once per
+                            // contribution: opacity on v[0..4] and v[9] (RAST:662), 0.5 on v[2..4], (1-opacity)*opacity on v[8]
+                            const float agg = ag * g;
+                            const float vs0 = agg * cix, vs1 = agg * ciy;       // RAST:664-665 without the opacity factor
                             v[0] += vs0; v[1] += vs1;
-                            v[2] = __builtin_fmaf(hg * cix, cix, v[2]);
-                            v[3] = __builtin_fmaf(hg * cix, ciy, v[3]);
-                            v[4] = __builtin_fmaf(hg * ciy, ciy, v[4]);
+                            v[2] = __builtin_fmaf(vs0, cix, v[2]);
+                            v[3] = __builtin_fmaf(vs0, ciy, v[3]);
+                            v[4] = __builtin_fmaf(vs1, ciy, v[4]);
                             v[5] = __builtin_fmaf(d_rgb, Q[qi].gr, v[5]);         // RAST:650
                             v[6] = __builtin_fmaf(d_rgb, Q[qi].gg, v[6]);
                             v[7] = __builtin_fmaf(d_rgb, Q[qi].gb, v[7]);
-                            v[8] = __builtin_fmaf((ag * g) * (1.0f - apt), apt, v[8]);   // RAST:658-661
+                            v[8] += agg;                                         // RAST:658-661
                             v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
                             v[10] += 1.0f;                                       // RAST:695-696
                             Q[qi].T = Tn;
-                            const float wgt = alpha * Tn;
-                            Q[qi].w0 = __builtin_fmaf(c4.x, wgt, Q[qi].w0);        // RAST:656
-                            Q[qi].w1 = __builtin_fmaf(c4.y, wgt, Q[qi].w1);
-                            Q[qi].w2 = __builtin_fmaf(c4.z, wgt, Q[qi].w2);
-                            Q[qi].tot0 += fabsf(vs0); Q[qi].tot1 += fabsf(vs1);    // RAST:666-667
+                            Q[qi].W = __builtin_fmaf(cg, d_rgb, Q[qi].W);        // RAST:656
+                            Q[qi].tot0 = __builtin_fmaf(fabsf(vs0), apt, Q[qi].tot0);   // RAST:666-667
+                            Q[qi].tot1 = __builtin_fmaf(fabsf(vs1), apt, Q[qi].tot1);
                         }
                     }
                     if (!any_use) continue;
@@ -366,6 +368,13 @@ __global__ __launch_bounds__(256) void k_bwd_points(
             const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
             s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
             s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
+        }
+        {   // the per-splat factors k_blend_bwd_tile left out (see there): opacity, 0.5, (1 - opacity) * opacity
+            const float apt = PB[m].z;
+            s[0] *= apt; s[1] *= apt; s[9] *= apt;
+            const float h = 0.5f * apt;
+            s[2] *= h; s[3] *= h; s[4] *= h;
+            s[8] *= (1.0f - apt) * apt;
         }
         const float guv0 = s[0], guv1 = s[1];
         const float g00 = s[2], g01 = s[3], g11 = s[4];
