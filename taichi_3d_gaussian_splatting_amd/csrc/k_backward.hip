@@ -117,7 +117,9 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     int tile_last = qlast[0];
 #pragma unroll
     for (int qi = 1; qi < NQ; ++qi) tile_last = max(tile_last, qlast[qi]);
-    const float px_lo = (float)(tile_u * 16 + lx) + 0.5f, py_lo = (float)(tile_v * 16 + ly) + 0.5f;
+    float pxq[NQ], pyq[NQ];                      // pixel centres of this lane in its NQ quadrants
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { pxq[qi] = rx0[qi] + (float)lx; pyq[qi] = ry0[qi] + (float)ly; }
 
     // entries at or beyond tile_last are dead for every pixel of the tile (RAST:609-610)
     for (int hi = min(end, tile_last); hi > start; hi -= 64) {
@@ -150,39 +152,44 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     GS_STAT(9, 1);
                     const float4 a4 = sRec[j][0], b4 = sRec[j][1], c4 = sRec[j][2];
                     const float a = a4.z, b = a4.w, c = b4.x, apt = b4.z;
-                    float v[11];
+                    float v[10];
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) v[k] = 0.0f;
-                    bool any_use = false;
+                    for (int k = 0; k < 10; ++k) v[k] = 0.0f;
+                    int n_use = 0;                                            // contributions of this splat in this tile (wave-uniform)
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi) {
                         if (!((mq[qi] >> j) & 1ull)) continue;                // wave-uniform
                         GS_STAT(10, 1);
-                        const int q = grp * NQ + qi;
-                        // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348 (same op order for p)
-                        const float dx = (px_lo + (float)((q & 1) * 8)) - a4.x, dy = (py_lo + (float)((q >> 1) * 8)) - a4.y;
-                        const float cix = a * dx + b * dy, ciy = b * dx + c * dy;
-                        const float exponent = -0.5f * (dx * cix + dy * ciy);
                         // lane predicates as wave-uniform SGPR masks (see k_blend_fwd)
                         const unsigned long long inr_m = gs_ballot((lo + j) < Q[qi].last);   // RAST:609-610
-                        if ((gs_ballot(!(exponent + 0.02f < c4.w)) & inr_m) == 0ull) continue;
+                        if (inr_m == 0ull) continue;
                         GS_STAT(11, 1);
-                        // exp: the hardware v_exp_f32 (1 ulp) unless some lane sits within 1e-5 (relative) of the
-                        // 1/255 threshold, where the reference polynomial decides (same decisions as the oracle)
+                        // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348.  Fast form (fused multiply-adds,
+                        // hardware v_exp_f32): alpha is within 2e-6 (relative) of the reference operation sequence, so unless
+                        // some lane sits within 1e-5 of the 1/255 threshold every keep/skip decision is already the oracle's;
+                        // otherwise the strict sequence and the reference polynomial decide.
+                        const float dx = pxq[qi] - a4.x, dy = pyq[qi] - a4.y;
+                        float cix, ciy, exponent;
+                        {
+#pragma clang fp contract(fast)
+                            cix = a * dx + b * dy; ciy = b * dx + c * dy;
+                            exponent = -0.5f * (dx * cix + dy * ciy);
+                        }
                         float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
                         float prod_alpha = g * apt;
                         if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
-                            g = gs_expf(exponent) * b4.y;
+                            const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
+                            g = gs_expf(-0.5f * (dx * sx + dy * sy)) * b4.y;
                             prod_alpha = g * apt;
                             GS_STAT(14, 1);
                         }
                         const unsigned long long use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;   // RAST:634
-                        any_use = any_use || (use_m != 0ull);
+                        n_use += __popcll(use_m);
                         GS_STAT(12, __popcll(use_m)); GS_STAT(15, use_m != 0ull ? 1 : 0);
                         if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing
                             // float outputs only from here on: let the compiler fuse multiply-adds
 #pragma clang fp contract(fast)
-                            const float alpha = prod_alpha < GS_ALPHA_MAX ? prod_alpha : GS_ALPHA_MAX;
+                            const float alpha = __builtin_amdgcn_fmed3f(prod_alpha, -__builtin_inff(), GS_ALPHA_MAX);   // min, RAST:636
                             const float one_m = 1.0f - alpha;
                             const float inv = __builtin_amdgcn_rcpf(one_m);
                             float Tn = Q[qi].T * inv;                              // RAST:643 (rcp + one correction)
@@ -204,24 +211,24 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             v[7] = __builtin_fmaf(d_rgb, Q[qi].gb, v[7]);
                             v[8] += agg;                                         // RAST:658-661
                             v[9] += __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);   // RAST:691-694
-                            v[10] += 1.0f;                                       // RAST:695-696
                             Q[qi].T = Tn;
                             Q[qi].W = __builtin_fmaf(cg, d_rgb, Q[qi].W);        // RAST:656
                             Q[qi].tot0 = __builtin_fmaf(fabsf(vs0), apt, Q[qi].tot0);   // RAST:666-667
                             Q[qi].tot1 = __builtin_fmaf(fabsf(vs1), apt, Q[qi].tot1);
                         }
                     }
-                    if (!any_use) continue;
+                    if (n_use == 0) continue;
                     GS_STAT(13, 1);
-                    // Sum the eleven values over the 64 lanes through a wave-private LDS transpose: 11 conflict-free
+                    // Sum the ten values over the 64 lanes through a wave-private LDS transpose: 10 conflict-free
                     // ds_write_b32, then lane 4k+s adds 16 floats of value k (4 ds_read_b128, row stride 68 floats
                     // keeps the reads conflict-free) and two quad DPP adds fold s.  About 30 VALU issue slots
-                    // instead of 130+ for six half-rate DPP steps on eleven registers.
+                    // instead of 130+ for six half-rate DPP steps on eleven registers.  The eleventh value, the
+                    // number of contributions (RAST:695-696), is the population count of the vote masks.
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) sRed[k * RED_STRIDE + lane] = v[k];
+                    for (int k = 0; k < 10; ++k) sRed[k * RED_STRIDE + lane] = v[k];
                     __builtin_amdgcn_wave_barrier();
                     float t = 0.0f;
-                    if (lane < 44) {
+                    if (lane < 40) {
                         const float4* src = reinterpret_cast<const float4*>(sRed + (lane >> 2) * RED_STRIDE + 16 * (lane & 3));
                         const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
                         t = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     }
                     t += gs_dpp<0xB1>(t);              // quad_perm [1,0,3,2]
                     t += gs_dpp<0x4E>(t);              // quad_perm [2,3,0,1]
+                    if (lane == 40) t = (float)n_use;
                     const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
                     if ((lane & 3) == 0 && lane < 48) partial[(size_t)sj * PW + (lane >> 2)] = t;   // 12 floats (pad = 0), one store
                     if (lane == 63) visited[sj] = 1;
