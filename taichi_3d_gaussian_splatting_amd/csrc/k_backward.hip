@@ -192,8 +192,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             const float alpha = __builtin_amdgcn_fmed3f(prod_alpha, -__builtin_inff(), GS_ALPHA_MAX);   // min, RAST:636
                             const float one_m = 1.0f - alpha;
                             const float inv = __builtin_amdgcn_rcpf(one_m);
-                            float Tn = Q[qi].T * inv;                              // RAST:643 (rcp + one correction)
-                            Tn = __builtin_fmaf(__builtin_fmaf(-one_m, Tn, Q[qi].T), inv, Tn);
+                            const float Tn = Q[qi].T * inv;                        // RAST:643 (v_rcp_f32: 1 ulp)
                             // d alpha: sum_c (colour_c*T - accumulated_c/(1-alpha)) * g_c, RAST:653-657, with the sums over c taken first
                             const float cg = c4.x * Q[qi].gr + c4.y * Q[qi].gg + c4.z * Q[qi].gb;
                             const float ag = Tn * cg - inv * Q[qi].W;
