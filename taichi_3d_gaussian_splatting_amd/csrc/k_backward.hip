@@ -170,11 +170,8 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         // otherwise the strict sequence and the reference polynomial decide.
                         const float dx = pxq[qi] - a4.x, dy = pyq[qi] - a4.y;
                         float cix, ciy, exponent;
-                        {
-#pragma clang fp contract(fast)
-                            cix = a * dx + b * dy; ciy = b * dx + c * dy;
-                            exponent = -0.5f * (dx * cix + dy * ciy);
-                        }
+                        cix = __builtin_fmaf(a, dx, b * dy); ciy = __builtin_fmaf(b, dx, c * dy);
+                        exponent = -0.5f * __builtin_fmaf(dx, cix, dy * ciy);
                         float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
                         float prod_alpha = g * apt;
                         if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
@@ -189,7 +186,8 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing
                             // float outputs only from here on: let the compiler fuse multiply-adds
 #pragma clang fp contract(fast)
-                            const float alpha = __builtin_amdgcn_fmed3f(prod_alpha, -__builtin_inff(), GS_ALPHA_MAX);   // min, RAST:636
+                            // min(prod_alpha, 0.99), RAST:636: both positive, so the integer minimum of the bit patterns (no canonicalise)
+                            const float alpha = __int_as_float(min(__float_as_int(prod_alpha), __float_as_int(GS_ALPHA_MAX)));
                             const float one_m = 1.0f - alpha;
                             const float inv = __builtin_amdgcn_rcpf(one_m);
                             const float Tn = Q[qi].T * inv;                        // RAST:643 (v_rcp_f32: 1 ulp)
@@ -237,7 +235,8 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     t += gs_dpp<0x4E>(t);              // quad_perm [2,3,0,1]
                     if (lane == 40) t = (float)n_use;
                     const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-                    if ((lane & 3) == 0 && lane < 48) partial[(size_t)sj * PW + (lane >> 2)] = t;   // 12 floats (pad = 0), one store
+                    float* row = partial + (size_t)sj * PW;
+                    if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
                     if (lane == 63) visited[sj] = 1;
                     __builtin_amdgcn_wave_barrier();
                 }
