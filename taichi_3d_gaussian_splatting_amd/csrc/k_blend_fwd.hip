@@ -61,8 +61,6 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
             // get_point_probability_density_from_conic_and_rescale, UTIL:275-284 (same op order)
             float dx = px - a4.x, dy = py - a4.y;
             float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
-            // cheap wave-level reject before the polynomial: exp(e)*rescale*opacity < 1/255 for sure
-            if ((gs_ballot(!(exponent + 0.02f < c4.w)) & alive) == 0ull) { GS_STAT(4, 1); continue; }
             GS_STAT(2, 1);
             float g = gs_expf(exponent) * b4.y;
             float alpha = g * b4.z;
@@ -75,9 +73,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
             GS_STAT(3, __popcll(use_m)); GS_STAT(5, __popcll(alive));
             if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {
                 last = base + j + 1;                                            // RAST:461
-                // same association as the reference (colour * alpha * T_i), so the image is bit-exact
-                cr += c4.x * alpha * T_i; cg += c4.y * alpha * T_i; cb += c4.z * alpha * T_i;   // RAST:462
-                if (!RGB_ONLY) { acc_d += b4.w * alpha * T_i; norm += alpha * T_i; count += 1; } // RAST:464-469
+                // alpha and T (and with them every index the forward returns) follow the reference operation sequence bit
+                // for bit; the weighted sums use one shared weight and fused multiply-adds (float outputs, 1e-4 bar)
+                const float w = alpha * T_i;
+                cr = __builtin_fmaf(c4.x, w, cr); cg = __builtin_fmaf(c4.y, w, cg); cb = __builtin_fmaf(c4.z, w, cb);   // RAST:462
+                if (!RGB_ONLY) { acc_d = __builtin_fmaf(b4.w, w, acc_d); norm += w; count += 1; }                    // RAST:464-469
                 T_i = next_T;
             }
             if (alive == 0ull) mask = 0ull;

@@ -35,8 +35,13 @@ def run_oracle(scene, q, t, cfg=None):
                           scene.point_object_id, q, t, scene.camera_intrinsics, scene.height, scene.width, cfg)
 
 
+IMAGE_TOL = 2e-6      # max |a - ref| / max |ref| of the blended images (fused multiply-adds, shared weight alpha*T)
+
+
 def assert_forward_parity(module, inp, outs, f, feat_after, rgb_only=False):
-    """Bit-exact on every integer array AND on every f32 array of the forward."""
+    """Bit-exact on every integer array and on every per-point f32 array of the forward (uv, conic, colour, radii ...,
+    which decide every index); the blended images (sums of up to thousands of terms) within IMAGE_TOL, fifty times
+    tighter than the 1e-4 bar; accumulated alpha (1 - T) bit-exact again because T follows the reference sequence."""
     image, depth, count = outs
     fr = module.last_frame
     assert fr.n_points_in_camera == f.M, (fr.n_points_in_camera, f.M)
@@ -51,10 +56,17 @@ def assert_forward_parity(module, inp, outs, f, feat_after, rgb_only=False):
             f"{name}: not bit-exact, max abs diff {np.abs(got - ref).max() if ref.size else 0}"
     # in-place quaternion normalisation, RAST:264-266
     assert np.array_equal(inp.point_cloud_features.detach().cpu().numpy().view(np.uint32), feat_after.view(np.uint32))
-    assert np.array_equal(image.detach().cpu().numpy().view(np.uint32), f.rasterized_image.view(np.uint32)), "image"
+    e = rel_err(image.detach().cpu().numpy(), f.rasterized_image)
+    assert e < IMAGE_TOL, ("image", e)
+    acc = module.last_forward_outputs["pixel_accumulated_alpha"].cpu().numpy() if not rgb_only else None
+    if acc is not None:
+        assert np.array_equal(acc.view(np.uint32), f.pixel_accumulated_alpha.view(np.uint32)), "pixel_accumulated_alpha"
+        assert np.array_equal(module.last_forward_outputs["pixel_offset_of_last_effective_point"].cpu().numpy(),
+                              f.pixel_offset_of_last_effective_point), "pixel_offset_of_last_effective_point"
     if not rgb_only:
         assert np.array_equal(count.cpu().numpy(), f.pixel_valid_point_count), "pixel_valid_point_count"
-        assert np.array_equal(depth.detach().cpu().numpy().view(np.uint32), f.rasterized_depth.view(np.uint32)), "depth"
+        e = rel_err(depth.detach().cpu().numpy(), f.rasterized_depth)
+        assert e < IMAGE_TOL, ("depth", e)
 
 
 def rel_err(a, ref):
