@@ -215,16 +215,20 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
             const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
             const bool valid = li < tile_n;
             const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
-            unsigned long long same = gs_ballot(valid);
+            // lanes with the same digit, as two 32-bit halves per lane: per bit one vote, then same &= ~(vote ^ m) with m = all
+            // ones where the lane's bit is set (v_bfe_i32, v_xnor_b32, v_and_b32 per half)
+            const unsigned long long vm = gs_ballot(valid);
+            uint32_t slo = (uint32_t)vm, shi = (uint32_t)(vm >> 32);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
-                const bool b = (d >> bit) & 1u;
-                const unsigned long long bal = gs_ballot(b);
-                same &= b ? bal : ~bal;
+                const int32_t mb = (int32_t)(d << (31 - bit)) >> 31;
+                const unsigned long long bal = gs_ballot(mb < 0);
+                slo &= ~((uint32_t)bal ^ (uint32_t)mb);
+                shi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)mb);
             }
-            const uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
+            const uint32_t in_round = (uint32_t)__popc(slo & (uint32_t)lt_mask) + (uint32_t)__popc(shi & (uint32_t)(lt_mask >> 32));
             const uint32_t before = valid ? cnt[wave][d] : 0u;
-            if (valid && in_round == 0) cnt[wave][d] = before + (uint32_t)__popcll(same);
+            if (valid && in_round == 0) cnt[wave][d] = before + (uint32_t)__popc(slo) + (uint32_t)__popc(shi);
             rank[r] = before + in_round;
         }
         __syncthreads();
