@@ -11,6 +11,7 @@
 // rebuild those.  HBM-bound integer work: no LDS reshaping beyond per-wave digit counters.
 #include "gs_common.h"
 #include "gs_scan.h"
+#include <type_traits>
 
 #define SORT_TILE 4096          // keys per tile: 256 threads x 16
 #define SORT_ROUNDS 16
@@ -194,10 +195,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     gbase[t] = hist_scanned[t * nblocks + blockIdx.x];
-    for (int tile = 0; tile < tiles_per_block; ++tile) {
-        const uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tile) * SORT_TILE;
-        if (tile_base >= n) break;
-        const uint32_t tile_n = (uint32_t)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
+    // one 4096-pair tile; FULL (every tile but the last of the array) drops all bounds predicates
+    auto do_tile = [&](auto full_tag, const uint64_t tile_base, const uint32_t tile_n) {
+        constexpr bool FULL = decltype(full_tag)::value;
         cnt[0][t] = 0; cnt[1][t] = 0; cnt[2][t] = 0; cnt[3][t] = 0;
         __syncthreads();
         KeyT k[SORT_ROUNDS];
@@ -206,14 +206,14 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
             const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            const bool valid = li < tile_n;
+            const bool valid = FULL || li < tile_n;
             k[r] = valid ? keys_in[tile_base + li] : (KeyT)0;
             v[r] = valid ? vals_in[tile_base + li] : 0;
         }
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
             const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            const bool valid = li < tile_n;
+            const bool valid = FULL || li < tile_n;
             const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
             // lanes with the same digit, as two 32-bit halves per lane: per bit one vote, then same &= ~(vote ^ m) with m = all
             // ones where the lane's bit is set (v_bfe_i32, v_xnor_b32, v_and_b32 per half)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
             const uint32_t li = (uint32_t)wave * (SORT_ROUNDS * 64) + r * 64 + lane;
-            if (li < tile_n) {
+            if (FULL || li < tile_n) {
                 const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
                 const uint32_t ipos = cnt[wave][d] + rank[r];
                 skeys[ipos] = k[r];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
 #pragma unroll
         for (int r = 0; r < SORT_ROUNDS; ++r) {
             const uint32_t idx = (uint32_t)r * 256u + t;
-            if (idx < tile_n) {
+            if (FULL || idx < tile_n) {
                 const KeyT kk = skeys[idx];
                 const uint32_t d = (uint32_t)(kk >> shift) & 255u;
                 const uint32_t pos = gbase[d] + (idx - dstart[d]);
@@ -271,6 +271,13 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
         __syncthreads();
         gbase[t] += tot;
         __syncthreads();
+    };
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tile) * SORT_TILE;
+        if (tile_base >= n) break;
+        const uint32_t tile_n = (uint32_t)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
+        if (tile_n == SORT_TILE) do_tile(std::true_type{}, tile_base, tile_n);
+        else do_tile(std::false_type{}, tile_base, tile_n);
     }
 }
 
