@@ -120,8 +120,8 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" const char* gs_kernel_names(void)
 {
-    return "k_pose_prepare,k_filter,k_scan_blocks,k_store_M,k_compact,k_project,k_keygen,k_sort_hist,k_scan_reduce,"
-           "k_scan_apply,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
+    return "k_pose_prepare,k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,k_sort_row_totals,"
+           "k_sort_rowscan,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
 }
 
 extern "C" int gs_create(int32_t device, gs_ctx** out)

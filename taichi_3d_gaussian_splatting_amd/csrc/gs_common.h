@@ -155,8 +155,8 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 
 // ---- optional per-kernel timing with HIP events on the launch stream -------------
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
-enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_SCAN_BLOCKS, KID_STORE_M, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
-                  KID_SORT_HIST, KID_SCAN_REDUCE, KID_SCAN_APPLY, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
+enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
+                  KID_SORT_HIST, KID_SORT_TOTALS, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
                   KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
@@ -190,7 +190,7 @@ struct GsBinArgs {
     void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64
     int key64;                                             // depth bits + tile bits > 32
     uint32_t* hist;                             // (256 * sort_blocks) + scratch
-    uint32_t* scan_tmp;                         // scratch for the scan
+    uint32_t* scan_tmp;                         // 256 digit totals of the current pass
     int32_t *tile_start, *tile_end; int T;
     void** keys_sorted; int32_t** vals_sorted;       // out: which of a/b holds the result
 };

@@ -10,7 +10,6 @@
 // is identical to sorting the reference's 64-bit (tile_id << 32) + depth_code keys; exports
 // rebuild those.  HBM-bound integer work: no LDS reshaping beyond per-wave digit counters.
 #include "gs_common.h"
-#include "gs_scan.h"
 #include <type_traits>
 
 #define SORT_TILE 4096          // keys per tile: 256 threads x 16
@@ -314,7 +313,7 @@ size_t gs_sort_hist_elems(uint32_t K)
     return (size_t)2 * 256 * nb;      // raw counts + scanned offsets
 }
 
-size_t gs_scan_tmp_elems(size_t n) { return 2 * ((n + GS_SCAN_CHUNK - 1) / GS_SCAN_CHUNK) + 16; }
+size_t gs_scan_tmp_elems(size_t) { return 256; }      // the 256 digit totals of k_sort_row_totals
 
 template <typename KeyT>
 static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
@@ -334,8 +333,8 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     for (int shift = 0; shift < a.key_bits; shift += 8) {
         uint32_t* offs = a.hist + (size_t)256 * nb;                 // second half of the table: scanned offsets
         GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
-        GS_TIMED(a.prof, KID_SCAN_REDUCE, s, k_sort_row_totals<<<256, 256, 0, s>>>(a.hist, a.scan_tmp, nb));
-        GS_TIMED(a.prof, KID_SCAN_APPLY, s, k_sort_rowscan<<<256, 1024, 0, s>>>(a.hist, a.scan_tmp, offs, nb));
+        GS_TIMED(a.prof, KID_SORT_TOTALS, s, k_sort_row_totals<<<256, 256, 0, s>>>(a.hist, a.scan_tmp, nb));
+        GS_TIMED(a.prof, KID_SORT_ROWSCAN, s, k_sort_rowscan<<<256, 1024, 0, s>>>(a.hist, a.scan_tmp, offs, nb));
         GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, offs, nb, tpb));
         KeyT* tk = kin; kin = kout; kout = tk;
         int32_t* tv = vin; vin = vout; vout = tv;

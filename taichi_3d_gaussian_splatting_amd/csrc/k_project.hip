@@ -1,13 +1,12 @@
 // k_project.hip -- per-point stages of the forward:
 //   k_pose_prepare   host prologue RAST:841-846 (inverse_SE3_qt_torch, UTIL:426-432) on device
 //   k_filter         filter_point_in_camera, RAST:31-78
-//   k_scan_blocks    exclusive scan of per-block counts (replaces torch mask-index / cumsum glue)
+//   k_scan_tiles_publish   exclusive scan of the per-block tile counts (replaces the torch cumsum glue) + hand-over of M, K
 //   k_compact        point_id[mask], RAST:861-870 (ascending ids)
 //   k_project        generate_point_attributes_in_camera_plane RAST:239-315 fused with
 //                    generate_num_overlap_tiles RAST:106-128
 // All HBM-bound streaming kernels; layouts in DESIGN.md.
 #include "gs_common.h"
-#include "gs_scan.h"
 
 #ifndef GS_RADIUS_FROM_PREBLUR_COV
 #define GS_RADIUS_FROM_PREBLUR_COV 1
@@ -349,6 +348,6 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters));
-    GS_TIMED(a.prof, KID_SCAN_BLOCKS, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
+    GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
                                                                               a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
 }

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"libgsrast.so does not export {n}"
     assert sorted(_native.SYMBOLS) == names
     assert L.gs_abi_version() == _native.ABI_VERSION
-    assert len(L.gs_kernel_names().decode().split(",")) == 17
+    assert len(L.gs_kernel_names().decode().split(",")) == 16
 
 
 def test_struct_layouts_match_the_header(tmp_path):
