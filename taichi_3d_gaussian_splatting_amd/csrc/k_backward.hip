@@ -37,11 +37,19 @@
 // workgroup: 2048 bins of width 1 (work >= 2047 shares the first bin).  Pure scheduling: results do
 // not depend on it.
 #define ORDER_BINS 2048
-__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order)
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order,
+                                                     uint4* __restrict__ clear, size_t clear_vec)
 {
     __shared__ uint32_t bins[ORDER_BINS];
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (blockIdx.x > 0) {
+        // the other workgroups of the launch clear the `visited` flags (and the all-zero row behind them) for the blend
+        // that follows: one launch instead of a memset plus this kernel
+        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + t; i < clear_vec; i += (size_t)(gridDim.x - 1) * 1024)
+            clear[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
     __syncthreads();
     for (int i = t; i < T; i += 1024) {
@@ -559,8 +567,11 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
-        (void)hipMemsetAsync(a.visited, 0, a.visited_bytes, s);      // flags + the shared all-zero row behind them
-        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order));
+        // workgroup 0 orders the tiles, the rest clear the flags + the shared all-zero row behind them (16-byte units)
+        const size_t clear_vec = (a.visited_bytes + 15) / 16;
+        const unsigned clear_groups = (unsigned)((clear_vec + 4095) / 4096 < 1024 ? (clear_vec + 4095) / 4096 : 1024);
+        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order,
+                                                                                         reinterpret_cast<uint4*>(a.visited), clear_vec));
         if (a.G == 1)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
                      a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
