@@ -160,6 +160,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 ctx.save_for_backward(pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
                                       q_pointcloud_camera, t_pointcloud_camera, acc_alpha, last)
                 ctx.mark_non_differentiable(count)
+                # the depth gradient is ignored (RAST:1157-1163) and the count has none: do not let autograd materialise
+                # two image-sized zero tensors (two fill launches) per backward for them
+                ctx.set_materialize_grads(False)
                 return image, depth, count
 
             @staticmethod
@@ -170,6 +173,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         raise RuntimeError("backward through a forward that ran without gradient tracking")
                     (pointcloud, pointcloud_features, point_invalid_mask, point_object_id, q_pointcloud_camera,
                      t_pointcloud_camera, acc_alpha, last) = ctx.saved_tensors
+                    if grad_rasterized_image is None:       # only the depth was used downstream: its gradient does not flow (RAST:1157-1163)
+                        grad_rasterized_image = torch.zeros(ctx.camera_info.camera_height, ctx.camera_info.camera_width, 3,
+                                                            dtype=torch.float32, device=pointcloud.device)
                     grad_pointcloud, grad_pointcloud_features = module._run_backward(
                         ctx.frame, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
                         q_pointcloud_camera, t_pointcloud_camera, ctx.camera_info, acc_alpha, last,

@@ -407,3 +407,15 @@ def test_point_counts_that_are_not_multiples_of_four(P, n):
     q, t = view_pose()
     module, inp, f, b, got = _fwd_bwd(P, s, q, t)
     assert inp.point_cloud_features.grad.data_ptr() % 16 == 0
+
+
+def test_backward_through_depth_only_gives_zero_gradients(P):
+    """The reference ignores the depth gradient (RAST:1157-1163); with unmaterialised grads the image gradient is None then."""
+    s = synth(500, 64, 64, 0.1, seed=3)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    inp = P.make_input(s, q, t)
+    image, depth, count = module(inp)
+    depth.sum().backward()
+    assert inp.point_cloud.grad is not None and not inp.point_cloud.grad.any()
+    assert not inp.point_cloud_features.grad.any()
