@@ -177,10 +177,9 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         // some lane sits within 1e-5 of the 1/255 threshold every keep/skip decision is already the oracle's;
                         // otherwise the strict sequence and the reference polynomial decide.
                         const float dx = pxq[qi] - a4.x, dy = pyq[qi] - a4.y;
-                        float cix, ciy, exponent;
-                        cix = __builtin_fmaf(a, dx, b * dy); ciy = __builtin_fmaf(b, dx, c * dy);
-                        exponent = -0.5f * __builtin_fmaf(dx, cix, dy * ciy);
-                        float g = __builtin_amdgcn_exp2f(exponent * 1.44269504088896341f) * b4.y;
+                        const float cix = __builtin_fmaf(a, dx, b * dy), ciy = __builtin_fmaf(b, dx, c * dy);
+                        // exp(-0.5 * q) = 2^(q * (-0.5 * log2 e)): one multiply instead of two
+                        float g = __builtin_amdgcn_exp2f(__builtin_fmaf(dx, cix, dy * ciy) * -0.72134752044448170f) * b4.y;
                         float prod_alpha = g * apt;
                         if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
                             const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
