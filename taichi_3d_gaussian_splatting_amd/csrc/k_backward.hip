@@ -1,15 +1,16 @@
 // k_backward.hip -- gaussian_point_rasterisation_backward, RAST:488-772, plus the torch
-// post-processing RAST:1102-1140, as two kernels and NO global atomics:
+// post-processing RAST:1102-1140, as three kernels and NO global atomics:
 //
 //   k_blend_bwd_tile  loop 1 (RAST:531-705).  One wave per tile walks the tile's list back to
 //                 front.  The 11 per-contribution quantities the reference sends to HBM with
 //                 ti.atomic_add (RAST:674-696) are summed over the tile's 256 pixels in
-//                 registers + DPP and stored ONCE per (point, tile) pair as a 12-float row of
-//                 `partial`, at the pair's pre-sort slot (offsets[p] + position of the tile in
-//                 p's tile box), so all rows of a point are contiguous; a byte of `visited`
-//                 marks the rows that were written.
-//   k_bwd_points  loop 2 (RAST:708-772) over all N rows: sums a point's visited rows in slot
-//                 order (deterministic), chains the Jacobians (GP3D:132-159, 237-331, 351-373),
+//                 registers + an LDS transpose and stored ONCE per (point, tile) pair as a 12-float
+//                 row of `partial`, at the pair's pre-sort slot (offsets[p] + position of the tile
+//                 in p's tile box), so all rows of a point are contiguous; a byte of `visited`
+//                 marks the rows that were written.  Factors that are constant per splat (opacity,
+//                 0.5, (1 - opacity) * opacity) are left out of the rows and applied once per point.
+//   k_sum_rows    sums a point's visited rows in slot order (deterministic).
+//   k_bwd_points  loop 2 (RAST:708-772) over all N rows: chains the Jacobians (GP3D:132-159, 237-331, 351-373),
 //                 applies band masks and grad factors (RAST:1102-1125, 1167-1182) and writes
 //                 every output row exactly once (zero for rows outside the frustum), including
 //                 the BackwardValidPointHookInput gathers (RAST:1128-1140).
@@ -24,14 +25,14 @@
 // ---------------------------------------------------------------------------------
 // Loop 1: ONE WAVE PER TILE, four pixels per lane (one per 8x8 quadrant).
 //   * no __syncthreads, no cross-wave combine: the wave sums a splat's contributions over its
-//     own 256 pixels (in-lane over the quadrants, then one DPP reduction) and lane 63 stores the
-//     48-byte row itself;
+//     own 256 pixels (in-lane over the quadrants, then an LDS transpose) and twelve lanes store the
+//     48-byte row with one instruction;
 //   * the four quadrants give every lane four independent T/w recurrences to interleave;
 //   * culling stays per quadrant: each lane tests its splat against the four 8x8 rectangles,
 //     four ballots, and a quadrant body runs only for the (splat, quadrant) pairs that survive.
 // Pairs that are never visited (beyond every pixel's last index -- about three quarters of a
 // saturated tile's list -- or culled in all four quadrants) cost nothing: their rows are not
-// written and their `visited` byte stays 0 (the array is cleared by a memset per backward).
+// written and their `visited` byte stays 0 (the array is cleared by the k_tile_order launch of each backward).
 // Tiles in order of decreasing backward work (entries to walk), so that the heaviest tiles are
 // dispatched first and the launch does not end on a few long-running waves.  Counting sort in one
 // workgroup: 2048 bins of width 1 (work >= 2047 shares the first bin).  Pure scheduling: results do
