@@ -559,6 +559,14 @@ extern "C" int gs_frame_release(gs_ctx* c, gs_frame* f)
 // ---- diagnostic build only (make stats): counters of the blend kernels, tools/blend_stats.py ----
 #ifdef GS_STATS
 __device__ unsigned long long gs_stats_counters[32];
+__device__ unsigned long long gs_stats_wave_times[2 * 65536];
+extern "C" int gs_debug_wave_times_read(unsigned long long* out, int n_waves)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (n_waves > 65536) n_waves = 65536;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_stats_wave_times), sizeof(unsigned long long) * 2 * (size_t)n_waves) != hipSuccess) return -2;
+    return 0;
+}
 extern "C" int gs_debug_stats_read(unsigned long long* out32, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -2;

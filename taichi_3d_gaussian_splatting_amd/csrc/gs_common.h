@@ -18,6 +18,7 @@
 // Diagnostic build only (`make stats` -> libgsrast_stats.so, tools/blend_stats.py): event counters of the two blend kernels.
 #ifdef GS_STATS
 extern __device__ unsigned long long gs_stats_counters[32];
+extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start, end (wall clock ticks) of each k_blend_bwd_tile wave
 #define GS_STAT(i, n) do { const unsigned long long gs_stat_n = (unsigned long long)(n); if (threadIdx.x % 64 == 0) atomicAdd(&gs_stats_counters[i], gs_stat_n); } while (0)
 #else
 #define GS_STAT(i, n) do { } while (0)

@@ -99,6 +99,9 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
     constexpr int G = 4 / NQ;
     const int tile = tile_order[blockIdx.x / G];
+#ifdef GS_STATS
+    const unsigned long long gs_t0 = wall_clock64();
+#endif
     // Tiles arrive heaviest first and the launch lasts about as long as the heaviest tile's wave does while it shares its
     // SIMD with four others: give the waves of the heaviest tiles a higher issue priority so that they are not the tail.
     if (blockIdx.x < (gridDim.x >> 3)) __builtin_amdgcn_s_setprio(3);
@@ -257,6 +260,9 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
             }
         }
     }
+#ifdef GS_STATS
+    if (lane == 0 && blockIdx.x < 65536) { gs_stats_wave_times[2 * blockIdx.x] = gs_t0; gs_stats_wave_times[2 * blockIdx.x + 1] = wall_clock64(); }
+#endif
     if (mag_image) {                                                            // RAST:700-704
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
