@@ -102,11 +102,6 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 #ifdef GS_STATS
     const unsigned long long gs_t0 = wall_clock64();
 #endif
-    // Tiles arrive heaviest first and the launch lasts about as long as the heaviest tile's wave does while it shares its
-    // SIMD with four others: give the waves of the heaviest tiles a higher issue priority so that they are not the tail.
-    if (blockIdx.x < (gridDim.x >> 3)) __builtin_amdgcn_s_setprio(3);
-    else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(2);
-    else if (blockIdx.x < (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
     const int grp = blockIdx.x % G;               // which NQ quadrants of the tile this wave owns
     const int lane = threadIdx.x;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
