@@ -33,6 +33,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
     const float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
     const float rx0 = (float)qx + 0.5f, ry0 = (float)qy + 0.5f;
     const int start = tile_start[tile], end = tile_end[tile];
+#ifdef GS_STATS
+    const unsigned long long gs_t0 = wall_clock64();
+#endif
 
     float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, acc_d = 0.0f, norm = 0.0f;
     int last = start, count = 0;
@@ -84,6 +87,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef GS_STATS
+    if (lane == 0 && blockIdx.x * 4 + wave < 65536) { gs_stats_wave_times[2 * (blockIdx.x * 4 + wave)] = gs_t0; gs_stats_wave_times[2 * (blockIdx.x * 4 + wave) + 1] = wall_clock64(); }
+#endif
     if (!inside) return;
     const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
     image[3 * o] = cr; image[3 * o + 1] = cg; image[3 * o + 2] = cb;
