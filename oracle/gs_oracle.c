@@ -619,6 +619,21 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
                  float* g_pc, float* g_feat, float* g_uv, float* mag, float* mag_img,
                  int32_t* n_affected, float* out_cov_buf, float* out_color_buf)
 {
+    return gso_backward_ex(f, pc, feat, obj, q_pc, t_pc, Km, grad_image, sh_band, cfg, g_pc, g_feat, g_uv, mag, mag_img,
+                           n_affected, out_cov_buf, out_color_buf, NULL, NULL);
+}
+
+/* The same, plus (optional) for every gradient element the MAGNITUDE OF WHAT WAS SUMMED to produce it: the sums of the
+ * absolute values of the loop-1 contributions (RAST:674-696), carried through the absolute values of the loop-2
+ * Jacobians and the grad factors.  A float accumulation can only be judged against that magnitude (an element whose
+ * terms cancel has no relative accuracy to speak of); the parity tests use it as the floor of their per-element bar. */
+int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, const int32_t* obj,
+                    const float* q_pc, const float* t_pc, const float* Km,
+                    const float* grad_image, int32_t sh_band, const gso_config* cfg,
+                    float* g_pc, float* g_feat, float* g_uv, float* mag, float* mag_img,
+                    int32_t* n_affected, float* out_cov_buf, float* out_color_buf,
+                    float* summed_pc, float* summed_feat)
+{
     (void)q_pc;
     const int64_t N = f->N, M = f->M;
     const int32_t W = f->W;
@@ -634,6 +649,10 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
     double* a_alpha = (double*)zalloc(sizeof(double) * (size_t)M);
     double* a_mag = (double*)zalloc(sizeof(double) * (size_t)M);
     int64_t* a_cnt = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
+    /* sums of |contribution|: uv 0..1, cov 2..4, colour 5..7, opacity 8 */
+    double* a_abs = summed_pc || summed_feat ? (double*)zalloc(sizeof(double) * 9 * (size_t)M) : NULL;
+    if (summed_pc) memset(summed_pc, 0, sizeof(float) * 3 * (size_t)N);
+    if (summed_feat) memset(summed_feat, 0, sizeof(float) * GSO_FEAT * (size_t)N);
 
     /* ---- loop 1, RAST:531-705; tiles in parallel, sums via atomic double adds ---- */
 #pragma omp parallel for schedule(dynamic, 1)
@@ -699,6 +718,13 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
                     GSO_ADD(a_alpha[p], opacity_grad);
                     GSO_ADD(a_mag[p], mg);
                     GSO_ADD(a_cnt[p], 1);
+                    if (a_abs) {
+                        double* ab = a_abs + 9 * (size_t)p;
+                        GSO_ADD(ab[0], fabsf(vs0)); GSO_ADD(ab[1], fabsf(vs1));
+                        GSO_ADD(ab[2], fabsf(cg00)); GSO_ADD(ab[3], fabsf(cg01)); GSO_ADD(ab[4], fabsf(cg11));
+                        GSO_ADD(ab[5], fabsf(gcol0)); GSO_ADD(ab[6], fabsf(gcol1)); GSO_ADD(ab[7], fabsf(gcol2));
+                        GSO_ADD(ab[8], fabsf(opacity_grad));
+                    }
 #undef GSO_ADD
                 }
             }
@@ -747,12 +773,36 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
                 else v = v * (i == 0 ? cfg->grad_color_factor : cfg->grad_high_order_color_factor);
                 gf[8 + 16 * ch + i] = v;
             }
+        if (a_abs) {
+            const double* ab = a_abs + 9 * (size_t)idx;
+            const double acov[4] = { ab[2], ab[3], ab[3], ab[4] };
+            if (summed_pc)
+                for (int j = 0; j < 3; ++j) summed_pc[3 * (size_t)pid + j] = (float)(ab[0] * fabsf(Jpos[j]) + ab[1] * fabsf(Jpos[3 + j]));
+            if (summed_feat) {
+                float* sf = summed_feat + (size_t)GSO_FEAT * pid;
+                for (int k = 0; k < 4; ++k) {
+                    double v = 0.0;
+                    for (int i = 0; i < 4; ++i) v += acov[i] * fabsf(dSq[4 * i + k]);
+                    sf[k] = (float)(v * fabsf(cfg->grad_q_factor));
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double v = 0.0;
+                    for (int i = 0; i < 4; ++i) v += acov[i] * fabsf(dSs[3 * i + k]);
+                    sf[4 + k] = (float)(v * fabsf(cfg->grad_s_factor));
+                }
+                sf[7] = (float)(ab[8] * fabsf(cfg->grad_alpha_factor));
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int i = 0; i < 16; ++i)
+                        sf[8 + 16 * ch + i] = i >= keep ? 0.0f
+                            : (float)(ab[5 + ch] * fabsf(jac[ch] * sh[i]) * fabsf(i == 0 ? cfg->grad_color_factor : cfg->grad_high_order_color_factor));
+            }
+        }
         g_uv[2 * (size_t)pid] = guv[0]; g_uv[2 * (size_t)pid + 1] = guv[1];
         mag[pid] = (float)a_mag[idx];
         n_affected[idx] = (int32_t)a_cnt[idx];
         if (out_cov_buf) { out_cov_buf[3 * idx] = gc0; out_cov_buf[3 * idx + 1] = gc1; out_cov_buf[3 * idx + 2] = gc2; }
         if (out_color_buf) { out_color_buf[3 * idx] = gcol[0]; out_color_buf[3 * idx + 1] = gcol[1]; out_color_buf[3 * idx + 2] = gcol[2]; }
     }
-    free(a_uv); free(a_cov); free(a_col); free(a_alpha); free(a_mag); free(a_cnt);
+    free(a_uv); free(a_cov); free(a_col); free(a_alpha); free(a_mag); free(a_cnt); free(a_abs);
     return 0;
 }

@@ -147,6 +147,22 @@ int gso_backward(const gso_frame* f,
                  float* magnitude_grad_viewspace_on_image, int32_t* num_affected_pixels,
                  float* grad_uv_cov_buffer, float* grad_color_buffer);
 
+/* gso_backward plus, optionally (each may be NULL), for every element of the two returned gradients the magnitude of
+ * what was summed to produce it: sum |loop-1 contribution| (RAST:674-696) carried through |loop-2 Jacobian| and the
+ * grad factors -- (N,3) and (N,56).  Floor of the tests' per-element bar. */
+int gso_backward_ex(const gso_frame* f,
+                    const float* point_cloud, const float* point_cloud_features,
+                    const int32_t* point_object_id,
+                    const float* q_pointcloud_camera, const float* t_pointcloud_camera,
+                    const float* camera_intrinsics,
+                    const float* grad_rasterized_image, int32_t color_max_sh_band,
+                    const gso_config* cfg,
+                    float* grad_pointcloud, float* grad_pointcloud_features,
+                    float* grad_viewspace, float* magnitude_grad_viewspace,
+                    float* magnitude_grad_viewspace_on_image, int32_t* num_affected_pixels,
+                    float* grad_uv_cov_buffer, float* grad_color_buffer,
+                    float* summed_pointcloud, float* summed_pointcloud_features);
+
 void gso_frame_free(gso_frame* f);
 int  gso_num_threads(void);
 

@@ -81,6 +81,8 @@ def lib():
                                   C.POINTER(Config)]
         L.gso_backward.restype = C.c_int
         L.gso_backward.argtypes = [C.POINTER(_Frame)] + [C.c_void_p] * 7 + [C.c_int32, C.POINTER(Config)] + [C.c_void_p] * 8
+        L.gso_backward_ex.restype = C.c_int
+        L.gso_backward_ex.argtypes = [C.POINTER(_Frame)] + [C.c_void_p] * 7 + [C.c_int32, C.POINTER(Config)] + [C.c_void_p] * 10
         L.gso_frame_free.argtypes = [C.POINTER(_Frame)]
         L.gso_num_threads.restype = C.c_int
         for name, nargs in [("gso_inverse_se3_qt", None), ("gso_rotation_matrix_from_quaternion", None),
@@ -249,8 +251,10 @@ def forward(point_cloud, point_cloud_features, point_invalid_mask, point_object_
     return out, feat
 
 
-def backward(fwd, grad_rasterized_image, color_max_sh_band=2, cfg=None, want_buffers=False):
-    """Reference backward (RAST:1025-1163) on a Forward from forward()."""
+def backward(fwd, grad_rasterized_image, color_max_sh_band=2, cfg=None, want_buffers=False, want_summed=False):
+    """Reference backward (RAST:1025-1163) on a Forward from forward().  want_summed adds "summed_pointcloud" (N,3) and
+    "summed_pointcloud_features" (N,56): per gradient element the sum of the absolute values of everything that was
+    added up to produce it (gso_backward_ex)."""
     cfg = cfg or default_config()
     pc, feat, obj, q, t, Km = fwd._inputs
     N, M, H, W = fwd.N, fwd.M, fwd.H, fwd.W
@@ -266,12 +270,17 @@ def backward(fwd, grad_rasterized_image, color_max_sh_band=2, cfg=None, want_buf
         "grad_uv_cov_buffer": np.zeros((max(M, 1), 3), np.float32),
         "grad_color_buffer": np.zeros((max(M, 1), 3), np.float32),
     }
-    rc = lib().gso_backward(fwd._handle, _p(pc), _p(feat), _p(obj), _p(q), _p(t), _p(Km), _p(g),
-                            int(color_max_sh_band), C.byref(cfg),
-                            _p(out["grad_pointcloud"]), _p(out["grad_pointcloud_features"]),
-                            _p(out["grad_viewspace"]), _p(out["magnitude_grad_viewspace"]),
-                            _p(out["magnitude_grad_viewspace_on_image"]), _p(out["num_affected_pixels"]),
-                            _p(out["grad_uv_cov_buffer"]), _p(out["grad_color_buffer"]))
+    if want_summed:
+        out["summed_pointcloud"] = np.zeros((N, 3), np.float32)
+        out["summed_pointcloud_features"] = np.zeros((N, 56), np.float32)
+    rc = lib().gso_backward_ex(fwd._handle, _p(pc), _p(feat), _p(obj), _p(q), _p(t), _p(Km), _p(g),
+                               int(color_max_sh_band), C.byref(cfg),
+                               _p(out["grad_pointcloud"]), _p(out["grad_pointcloud_features"]),
+                               _p(out["grad_viewspace"]), _p(out["magnitude_grad_viewspace"]),
+                               _p(out["magnitude_grad_viewspace_on_image"]), _p(out["num_affected_pixels"]),
+                               _p(out["grad_uv_cov_buffer"]), _p(out["grad_color_buffer"]),
+                               _p(out["summed_pointcloud"]) if want_summed else None,
+                               _p(out["summed_pointcloud_features"]) if want_summed else None)
     if rc != 0:
         raise RuntimeError("gso_backward failed")
     for k in ("num_affected_pixels", "grad_uv_cov_buffer", "grad_color_buffer"):

@@ -416,10 +416,13 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         float tz = ((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2];
         float d[6] = { Km[0] / tz, Km[1] / tz, (-Km[0] * tx - Km[1] * ty) / (tz * tz),
                        Km[3] / tz, Km[4] / tz, (-Km[3] * tx - Km[4] * ty) / (tz * tz) };
-        float gcam[3] = { guv0 * d[0] + guv1 * d[3], guv0 * d[1] + guv1 * d[4], guv0 * d[2] + guv1 * d[5] };
         float gt[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) gt[j] = gcam[0] * P.R[j] + gcam[1] * P.R[3 + j] + gcam[2] * P.R[6 + j];   // RAST:757
+        for (int j = 0; j < 3; ++j) {                                   // (d uv/d p_cam . W) first, GP3D:157-159, then RAST:757
+            const float j0 = (d[0] * P.R[j] + d[1] * P.R[3 + j]) + d[2] * P.R[6 + j];
+            const float j1 = (d[3] * P.R[j] + d[4] * P.R[3 + j]) + d[5] * P.R[6 + j];
+            gt[j] = guv0 * j0 + guv1 * j1;
+        }
         // ---- d Sigma' / d(q, s), GP3D:237-331, contracted with (g00 g01; g01 g11) ----
         const float4 pd = PD[m];                                        // translation_camera, RAST:737-738
         const float fx = Km[0], fy = Km[4];
@@ -444,22 +447,12 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) Mm[3 * i + j] = R[3 * i + j] * es[j];       // M = R S, GP3D:257
-        float UM[6];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) UM[3 * a + j] = U[3 * a] * Mm[j] + U[3 * a + 1] * Mm[3 + j] + U[3 * a + 2] * Mm[6 + j];
-        float gUM[6];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { gUM[j] = g00 * UM[j] + g01 * UM[3 + j]; gUM[3 + j] = g01 * UM[j] + g11 * UM[3 + j]; }
-        float GM[9];   // dL/dM = 2 U^T g (U M)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) GM[3 * i + j] = 2.0f * (U[i] * gUM[j] + U[3 + i] * gUM[3 + j]);
-        float gs_[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) gs_[j] = (GM[j] * R[j] + GM[3 + j] * R[3 + j] + GM[6 + j] * R[6 + j]) * es[j];   // GP3D:297-313
+        // d Sigma'/d M = (U (x) U)(4x9) . d Sigma/d M (9x9), then . dM/dq (9x4) and . dM/dS . dS/ds (GP3D:270-330), and only
+        // then the contraction with the accumulated (g00 g01; g01 g11) (RAST:716-721, 760-761): the reference's own
+        // product order, every sum left to right over the inner index with the structural zeros of the tables left out
+        // (adding an exact zero changes nothing).  A closed form (dL/dM = 2 U^T g U M) is shorter and, for a huge,
+        // strongly anisotropic splat, more accurate -- but then it is not the reference's f32 result: the 4x4 and 4x3
+        // Jacobians of such a splat hold large entries that cancel in the final contraction, and the reference rounds them first.
         const float sx = es[0], sy = es[1], sz = es[2];
         // dM/dq, GP3D:319-329 (rows = M entries 00 01 02 10 11 12 20 21 22; columns = q x y z w)
         const float dMdq[36] = {
@@ -472,11 +465,46 @@ __global__ __launch_bounds__(256) void k_bwd_points(
             2 * sx * qz, -2 * sx * qw, 2 * sx * qx, -2 * sx * qy,
             2 * sy * qw, 2 * sy * qz, 2 * sy * qy, 2 * sy * qx,
             -4 * sz * qx, -4 * sz * qy, 0.0f, 0.0f };
-        float gq[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const float gcov[4] = { g00, g01, g01, g11 };
+        float gq[4], gs_[3];
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
+        for (int i = 0; i < 4; ++i) {
+            // row i of d Sigma'/d Sigma (GP3D:270-279): entry 3a+b is U[i>>1][a] * U[i&1][b] for rows 0, 1, 3 and
+            // U[0][b] * U[1][a] for row 2
+            float D[9];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gq[k] += GM[e] * dMdq[4 * e + k];
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb)
+                    D[3 * a + bb] = i == 2 ? U[bb] * U[3 + a] : U[3 * (i >> 1) + a] * U[3 * (i & 1) + bb];
+            float Pm[9];                                          // row i of d Sigma'/d M, GP3D:294
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const float m0 = Mm[bb], m1 = Mm[3 + bb], m2 = Mm[6 + bb];
+                Pm[bb] = (((D[0] * (2.0f * m0) + D[1] * m1) + D[2] * m2) + D[3] * m1) + D[6] * m2;
+                Pm[3 + bb] = (((D[1] * m0 + D[3] * m0) + D[4] * (2.0f * m1)) + D[5] * m2) + D[7] * m2;
+                Pm[6 + bb] = (((D[2] * m0 + D[5] * m1) + D[6] * m0) + D[7] * m1) + D[8] * (2.0f * m2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                         // row i of d Sigma'/dq, GP3D:330
+                float acc = 0.0f;
+                bool first = true;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const bool zero = (e == 0 && (k == 0 || k == 3)) || (e == 4 && (k == 1 || k == 3)) || (e == 8 && k >= 2);
+                    if (zero) continue;
+                    const float term = Pm[e] * dMdq[4 * e + k];
+                    acc = first ? term : acc + term;
+                    first = false;
+                }
+                gq[k] = i == 0 ? gcov[0] * acc : gq[k] + gcov[i] * acc;     // RAST:760
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                         // row i of d Sigma'/ds, GP3D:297-313
+                const float acc = ((Pm[c] * R[c] + Pm[3 + c] * R[3 + c]) + Pm[6 + c] * R[6 + c]) * es[c];
+                gs_[c] = i == 0 ? gcov[0] * acc : gs_[c] + gcov[i] * acc;   // RAST:761
+            }
+        }
         // ---- colour, GP3D:351-373 with the backward's ray origin (RAST:731-732, 749) ----
         float dx = x - P.origin_bwd[0], dy = y - P.origin_bwd[1], dz = z - P.origin_bwd[2];
         float dn = sqrtf(dx * dx + dy * dy + dz * dz);

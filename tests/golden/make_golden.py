@@ -1,8 +1,8 @@
 """Mint golden vectors from the reference's own pure-torch helpers.
 
 Run ONCE in the build container (needs /root/reference; never runs on the GPU
-box, never imported by the tests).  Output: tests/golden/reference_torch_helpers.json
--- data only (inputs + expected outputs).
+box, never imported by the tests).  Output: tests/golden/reference_torch_helpers.json and
+tests/golden/reference_single_point_batch.json -- data only (inputs + expected outputs).
 
 What is executed: the plain-PyTorch helper functions of the reference's
 taichi_3d_gaussian_splatting/utils.py (torch_single_point_alpha_forward :513-558,
@@ -140,6 +140,84 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_torch_helpers.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
+    print("wrote", path)
+    single_point_batch(U)
+
+
+N_BATCH = 96
+
+
+def _run_single_point(U, dtype, T, Km, xyz, q, s, opacity_logit, pixel):
+    """torch_single_point_alpha_forward (utils.py:513-558) + autograd, evaluated in `dtype`.  The helper builds J
+    with torch.tensor([...]) (default dtype, detached: no gradient reaches xyz through J, like RAST:708-772), so the
+    default dtype is switched for the call instead of touching the helper."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        tx = torch.tensor(xyz.astype(npdt), requires_grad=True)
+        f = torch.tensor(np.concatenate([q, s, [opacity_logit]]).astype(npdt), requires_grad=True)
+        import warnings
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = U.torch_single_point_alpha_forward(
+                point_xyz=tx, point_q=f[:4], point_s=f[4:7], T_camera_pointcloud=torch.tensor(T.astype(npdt)),
+                camera_intrinsics=torch.tensor(Km.astype(npdt)), point_alpha=f[7], pixel_uv=torch.tensor(pixel))
+            a.backward()
+        return float(a.item()), tx.grad.double().tolist(), f.grad.double().tolist()
+    finally:
+        torch.set_default_dtype(old)
+
+
+def single_point_batch(U):
+    """N_BATCH seeded (point, pose, intrinsics, pixel) cases through the reference's single-point helper: alpha and all
+    eight Jacobian groups d alpha / d(xyz, q, s, opacity logit).  Every input is an exact float32 value.  Expected values
+    are the helper evaluated in float64; the helper evaluated in float32 (the precision the reference's own test
+    tests/GaussianPointCloudRasterisation_test.py:353-548 runs it in) is recorded beside them as the arithmetic's own
+    noise level.  Varied: pose rotation up to 26 degrees about a random axis + translation, fx != fy, principal point,
+    off-axis points 1.5 to 6 units in front of the camera, random quaternions (every fourth one NOT unit: the helper and
+    rotation_matrix_from_quaternion GaussianPoint3D.py:30-48 both use the raw formula), scales 0.02 to 0.8 per axis
+    (anisotropy up to 40:1), opacity logits -2 to 4, pixels up to two pixels off the projected centre."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(20261004)
+    cases = []
+    for i in range(N_BATCH):
+        ang = rng.uniform(0, 0.45)
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_rotvec(ang * ax).as_matrix()
+        T[:3, 3] = rng.uniform(-1, 1, 3) * np.array([0.5, 0.5, 1.0])
+        T = T.astype(np.float32)
+        fx, fy = rng.uniform(20, 60, 2)
+        cx, cy = rng.uniform(10, 22, 2)
+        Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+        p_cam = np.array([rng.uniform(-1.2, 1.2), rng.uniform(-1.2, 1.2), rng.uniform(1.5, 6.0)])
+        xyz = (np.linalg.inv(T.astype(np.float64)) @ np.append(p_cam, 1.0))[:3].astype(np.float32)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if i % 4 == 3:
+            q *= rng.uniform(0.9, 1.1)
+        q = q.astype(np.float32)
+        s = np.log(rng.uniform(0.02, 0.8, 3)).astype(np.float32)
+        opacity_logit = np.float32(rng.uniform(-2, 4))
+        pc = (T.astype(np.float64) @ np.append(xyz.astype(np.float64), 1.0))[:3]
+        uv = (Km.astype(np.float64) @ pc)[:2] / pc[2]
+        pixel = [int(np.floor(uv[0] + rng.uniform(-2, 2))), int(np.floor(uv[1] + rng.uniform(-2, 2)))]
+        a64, gx64, gf64 = _run_single_point(U, torch.float64, T, Km, xyz, q, s, opacity_logit, pixel)
+        a32, gx32, gf32 = _run_single_point(U, torch.float32, T, Km, xyz, q, s, opacity_logit, pixel)
+        cases.append({
+            "T_camera_pointcloud": T.astype(np.float64).tolist(), "camera_intrinsics": Km.astype(np.float64).tolist(),
+            "xyz": xyz.astype(np.float64).tolist(), "q_xyzw": q.astype(np.float64).tolist(),
+            "log_s": s.astype(np.float64).tolist(), "opacity_logit": float(opacity_logit), "pixel_uv": pixel,
+            "float64": {"alpha": a64, "grad_xyz": gx64, "grad_q_s_opacity": gf64},
+            "float32": {"alpha": a32, "grad_xyz": gx32, "grad_q_s_opacity": gf32}})
+    out = {"source": "utils.py:513-558 (torch_single_point_alpha_forward) + torch.autograd, inputs seeded: "
+                     "numpy default_rng(20261004), see make_golden.py:single_point_batch",
+           "cases": cases}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_single_point_batch.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=0)
     print("wrote", path)
 
 

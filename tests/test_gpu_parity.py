@@ -419,3 +419,51 @@ def test_backward_through_depth_only_gives_zero_gradients(P):
     depth.sum().backward()
     assert inp.point_cloud.grad is not None and not inp.point_cloud.grad.any()
     assert not inp.point_cloud_features.grad.any()
+
+
+@pytest.mark.parametrize("seed", [60163, 60266])
+def test_soak_seeds_with_ill_conditioned_splats(P, seed):
+    """The two scenes of round 1's parity soak (tools/parity_soak.py; narrow, tall images full of huge anisotropic
+    splats) where the HIP kernel -- then a closed form for dL/dM -- and the oracle -- the reference's 4x9 . 9x9 . 9x4
+    product order, GP3D:270-330, in f32 -- were 1.09e-4 / 1.14e-4 of the tensor maximum apart on the scale gradient, and a
+    float64 autograd restatement had to arbitrate.  k_bwd_points now follows the reference's product order too, so the
+    comparison that counts (HIP vs oracle) passes on its own; the float64 numbers are recorded beside it to show what the
+    reference's f32 operation order costs on such splats: both f32 results sit ~1e-4 from float64, together."""
+    import json
+    import os
+    c = P.soak_case(seed)
+    s, q, t, partial, rng = c["scene"], c["q"], c["t"], c["partial"], c["rng"]
+    unit = dict(grad_color_factor=1.0, grad_high_order_color_factor=1.0, grad_s_factor=1.0, grad_q_factor=1.0, grad_alpha_factor=1.0)
+    cfg = P.Rast.GaussianPointCloudRasterisationConfig()
+    cfg.allow_partial_tiles = partial
+    for k, v in unit.items():
+        setattr(cfg, k, v)
+    module = P.Rast(cfg)
+    inp = P.make_input(s, q, t, 3)
+    ocfg = oracle.default_config(allow_partial_tiles=int(partial), **unit)
+    f, feat_after = P.run_oracle(s, q, t, ocfg)
+    outs = module(inp)
+    P.assert_forward_parity(module, inp, outs, f, feat_after)
+    image = outs[0]
+    target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
+    g = 2.0 * (image.detach() - target)
+    image.backward(g)
+    b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3, None, ocfg)      # HIP vs oracle: tensor-level AND per element
+    ref_pc, ref_ft = P.float64_autograd_gradients(s, q, t, f, feat_after, g.cpu().numpy())
+    gp, gf = inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()
+    op, of = b["grad_pointcloud"], b["grad_pointcloud_features"]
+    report = {"seed": seed, "image": [c["W"], c["H"]], "points_in_camera": int(f.M), "metric": "max |a - b| / max |b| per column group"}
+    # SH columns are left out of the float64 comparison: the restatement evaluates the colour with the forward's ray origin,
+    # the reference's backward with t_pointcloud_camera (RAST:731-732), which differ for the non-unit pose quaternion used here
+    for name, a_hip, a_orc, a_f64 in [("xyz", gp, op, ref_pc), ("q", gf[:, 0:4], of[:, 0:4], ref_ft[:, 0:4]),
+                                      ("s", gf[:, 4:7], of[:, 4:7], ref_ft[:, 4:7]), ("opacity", gf[:, 7:8], of[:, 7:8], ref_ft[:, 7:8])]:
+        report[name] = {"hip_vs_oracle": P.rel_err(a_hip, a_orc), "hip_vs_float64": P.rel_err(a_hip, a_f64),
+                        "oracle_vs_float64": P.rel_err(a_orc, a_f64)}
+        assert report[name]["hip_vs_oracle"] < 1e-5, (name, report[name])          # same operation order: far inside the 1e-4 bar
+        # what f32 in the reference's product order costs here; HIP and oracle pay it together
+        assert report[name]["hip_vs_float64"] < 3e-4 and report[name]["oracle_vs_float64"] < 3e-4, (name, report[name])
+    report["per_element_bar_use"] = {k: v["bar_use_max"] for k, v in b["margins"].items()}
+    os.makedirs(os.path.join(P.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(P.ROOT, "gpurun_out", f"soak_seed_{seed}.json"), "w") as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))

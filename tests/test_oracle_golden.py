@@ -87,6 +87,63 @@ def test_single_point_alpha_and_jacobians(golden):
     assert np.allclose(got, g["grad_features_0_8"], atol=tol["grad_features_atol"])
 
 
+def _oracle_single_point(c):
+    """The oracle's per-point chain for one fixture case, composed exactly as the reference's backward composes it
+    (RAST:708-772: d alpha/d uv through GP3D:132-159, d alpha/d cov through GP3D:237-331), in f32 where the oracle is f32."""
+    T = np.array(c["T_camera_pointcloud"], np.float32)
+    Km = np.array(c["camera_intrinsics"], np.float32)
+    xyz = np.array(c["xyz"], np.float32)
+    q, s = np.array(c["q_xyzw"], np.float32), np.array(c["log_s"], np.float32)
+    pcam = (T @ np.append(xyz, np.float32(1.0)).astype(np.float32))[:3]
+    uv = (Km @ pcam)[:2] / pcam[2]
+    cov = oracle.project_to_camera_covariance(q, s, T, Km, pcam).astype(np.float64)
+    p, dp_dmean, dp_dcov = _normalized_2d(np.array(c["pixel_uv"], np.float64) + 0.5, uv.astype(np.float64), cov)
+    opacity = 1.0 / (1.0 + float(oracle.expf(np.float32(-c["opacity_logit"]))))
+    J_uv = oracle.project_to_camera_position_jacobian(xyz, T, Km).astype(np.float64)
+    dSq, dSs = oracle.project_to_camera_covariance_jacobian(q, s, T, Km, pcam)
+    flat = np.array([dp_dcov[0, 0], dp_dcov[0, 1], dp_dcov[1, 0], dp_dcov[1, 1]])
+    return (p * opacity, opacity * dp_dmean @ J_uv,
+            np.concatenate([opacity * flat @ dSq.astype(np.float64), opacity * flat @ dSs.astype(np.float64),
+                            [p * (1 - opacity) * opacity]]))
+
+
+def _vec_rel(a, ref):
+    a, ref = np.atleast_1d(np.asarray(a, np.float64)), np.atleast_1d(np.asarray(ref, np.float64))
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def test_single_point_batch_against_reference_helper():
+    """96 seeded cases minted by running the reference's torch_single_point_alpha_forward (utils.py:513-558) + autograd
+    (tests/golden/make_golden.py:single_point_batch): the oracle's f32 chain against the helper evaluated in FLOAT64,
+    five groups per case -- alpha, d alpha/d xyz, /d q, /d s, /d opacity logit (all eight Jacobian columns of the
+    reference's test) -- each within 1e-5 of the group's largest entry.  The fixture also holds the helper evaluated in
+    float32, the precision the reference's own test runs it in; its distance from float64 is the arithmetic's own
+    noise.  Where that noise is itself around 1e-5 (four cases: a sub-pixel eigenvalue of the un-blurred covariance,
+    alpha = 1e-4, a 90:1 conditioned covariance) the oracle has to stay within twice the reference's own float32
+    error; nowhere is it further than 1.5e-5.  The reference's test accepts 1e-4 / 1e-4 / 1e-2 absolute."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_single_point_batch.json")) as fh:
+        cases = json.load(fh)["cases"]
+    assert len(cases) >= 64
+    groups = [("alpha", None), ("xyz", None), ("q", slice(0, 4)), ("s", slice(4, 7)), ("opacity", slice(7, 8))]
+    errs = np.zeros((len(cases), 5))
+    noise = np.zeros((len(cases), 5))
+    for i, c in enumerate(cases):
+        a, gx, gf = _oracle_single_point(c)
+        r64, r32 = c["float64"], c["float32"]
+        g64, g32 = np.array(r64["grad_q_s_opacity"]), np.array(r32["grad_q_s_opacity"])
+        got = [a, gx, gf[0:4], gf[4:7], gf[7:8]]
+        want = [r64["alpha"], r64["grad_xyz"], g64[0:4], g64[4:7], g64[7:8]]
+        ref32 = [r32["alpha"], r32["grad_xyz"], g32[0:4], g32[4:7], g32[7:8]]
+        for k in range(5):
+            errs[i, k], noise[i, k] = _vec_rel(got[k], want[k]), _vec_rel(ref32[k], want[k])
+            assert errs[i, k] <= max(1e-5, 2.0 * noise[i, k]), (i, groups[k][0], errs[i, k], noise[i, k])
+    assert errs.max() < 1.5e-5
+    assert (errs.max(axis=1) > 1e-5).sum() <= 4 and np.median(errs.max(axis=1)) < 2e-6
+    assert np.all(np.median(errs, axis=0) <= 1.5 * np.median(noise, axis=0) + 1e-8)   # as accurate as the reference's own f32 run
+
+
 def test_feature_row_layout():
     """reference tests :54-104: [0:4] q, [4:7] log-scale, [7] opacity logit, [8:24]/[24:40]/[40:56] SH.
     A one-point scene: colour must come from exactly those slices."""

@@ -1,6 +1,6 @@
 """Randomised parity soak (GPU): many seeded scenes of varied size, density, splat scale, pose, SH band and image
 shape (including partial edge tiles) through the C ABI against the CPU oracle, with the bars of tests/test_gpu_parity.py
-(integers and forward f32 bit-exact, gradients 1e-4 of the tensor maximum).  Not part of the test suite (minutes).
+(integers and forward f32 bit-exact, gradients 1e-4 of the tensor maximum and the per-element bar of tests/parity_util.py).  Not part of the test suite (minutes).
 
     python tools/parity_soak.py [n_cases] [first_seed]
 """
@@ -20,19 +20,8 @@ from taichi_3d_gaussian_splatting_amd.synthetic import synth  # noqa: E402
 
 
 def one(seed):
-    rng = np.random.default_rng(seed)
-    partial = bool(rng.integers(0, 2))
-    W = int(rng.integers(1, 40)) * 16 + (int(rng.integers(1, 16)) if partial else 0)
-    H = int(rng.integers(1, 30)) * 16 + (int(rng.integers(1, 16)) if partial else 0)
-    n = int(10 ** rng.uniform(1.5, 4.7))
-    sigma0 = float(10 ** rng.uniform(-2.3, -0.2))
-    band = int(rng.integers(0, 4))
-    s = synth(n, W, H, sigma0, sh_deg=3, seed=seed)
-    if rng.random() < 0.3:
-        s.point_invalid_mask[rng.random(n) < 0.2] = 1
-    ang = rng.normal(0, 0.15, 3)
-    q = np.array([[ang[0], ang[1], ang[2], 1.0]], np.float32) * float(rng.uniform(0.5, 2.0))    # deliberately not unit
-    t = rng.normal(0, 0.3, (1, 3)).astype(np.float32)
+    c = P.soak_case(seed)
+    s, q, t, band, partial, rng = c["scene"], c["q"], c["t"], c["band"], c["partial"], c["rng"]
     cfg = P.Rast.GaussianPointCloudRasterisationConfig()
     cfg.allow_partial_tiles = partial
     got = {}
@@ -46,48 +35,12 @@ def one(seed):
     target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
     g = 2.0 * (image.detach() - target)
     image.backward(g)
-    note = ""
-    try:
-        P.assert_backward_parity(module, inp, g.cpu().numpy(), f, band, module.last_backward_extras, ocfg)
-    except AssertionError as e:
-        # The oracle evaluates the per-point Jacobian chain in f32 in the reference's operation order; for an ill-conditioned
-        # splat (huge, strongly anisotropic) that alone can be 1e-4 of the tensor maximum away from the exact value.  A
-        # float64 autograd restatement (tests/torch_ref.py, CPU, slow) arbitrates: the GPU has to be within the bar of IT.
-        worst = arbitrate(s, q, t, rng_state_target=target.cpu().numpy(), partial=partial)
-        if worst >= P.GRAD_TOL:
-            raise AssertionError(f"{e}; against float64 autograd: {worst:.3e}")
-        note = f" [oracle-limited case: oracle check said {e}, GPU vs float64 autograd {worst:.2e}]"
-    return dict(seed=seed, W=W, H=H, n=n, sigma0=round(sigma0, 4), band=band, M=f.M, K=f.K, note=note)
-
-
-def arbitrate(s, q, t, rng_state_target, partial):
-    """max over the gradient tensors of |GPU - float64 autograd| / max|float64|, all grad factors 1, all SH bands."""
-    import torch_ref
-    cfg = P.Rast.GaussianPointCloudRasterisationConfig()
-    cfg.allow_partial_tiles = partial
-    cfg.grad_color_factor = cfg.grad_high_order_color_factor = cfg.grad_s_factor = cfg.grad_q_factor = cfg.grad_alpha_factor = 1.0
-    module = P.Rast(cfg)
-    inp = P.make_input(s, q, t, 3)
-    ocfg = oracle.default_config(allow_partial_tiles=int(partial), grad_color_factor=1.0, grad_high_order_color_factor=1.0,
-                                 grad_s_factor=1.0, grad_q_factor=1.0, grad_alpha_factor=1.0)
-    f, feat_after = P.run_oracle(s, q, t, ocfg)
-    image = module(inp)[0]
-    g = 2.0 * (image.detach() - torch.tensor(rng_state_target, device=image.device))
-    image.backward(g)
-    pc = torch.tensor(s.point_cloud, dtype=torch.float64, requires_grad=True)
-    ft = torch.tensor(feat_after, dtype=torch.float64, requires_grad=True)
-    img, _ = torch_ref.render(pc, ft, q, t, s.camera_intrinsics, s.height, s.width, f)
-    img.backward(g.cpu().double())
-    worst = P.rel_err(inp.point_cloud.grad.cpu().numpy(), pc.grad.numpy())
-    gf, rf = inp.point_cloud_features.grad.cpu().numpy(), ft.grad.numpy()
-    for lo, hi in [(0, 4), (4, 7), (7, 8)]:
-        worst = max(worst, P.rel_err(gf[:, lo:hi], rf[:, lo:hi]))
-    # SH gradients: the float64 restatement evaluates the colour with the forward's ray origin, the reference's backward with
-    # t_pointcloud_camera (RAST:731-732), which differ for the non-unit pose quaternions used here; they are well conditioned
-    # and stay on the oracle's bar
-    b = oracle.backward(f, g.cpu().numpy(), 3, ocfg)
-    worst = max(worst, P.rel_err(gf[:, 8:56], b["grad_pointcloud_features"][:, 8:56]))
-    return worst
+    # tensor-level 1e-4 AND the per-element bar, against the oracle alone: the per-point Jacobian chain of the HIP kernel
+    # follows the reference's product order like the oracle does, so no float64 arbitration is needed any more (the two
+    # seeds that needed it in round 1 are tests/test_gpu_parity.py::test_soak_seeds_with_ill_conditioned_splats)
+    b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, band, module.last_backward_extras, ocfg)
+    use = max(m["bar_use_max"] for m in b["margins"].values())
+    return dict(seed=seed, W=c["W"], H=c["H"], n=c["n"], sigma0=round(c["sigma0"], 4), band=band, M=f.M, K=f.K, bar_use=round(use, 3))
 
 
 def main():
@@ -96,8 +49,7 @@ def main():
     t0 = time.time()
     for i in range(n_cases):
         info = one(first + i)
-        note = info.pop("note")
-        print(f"ok {info}{note}  [{time.time() - t0:.0f} s]", flush=True)
+        print(f"ok {info}  [{time.time() - t0:.0f} s]", flush=True)
     print(f"{n_cases} cases passed")
 
 
