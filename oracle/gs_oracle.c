@@ -702,6 +702,7 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
                     float ag0 = (col[0] * T_i - w0 / one_m) * gr;   /* RAST:653-654 */
                     float ag1 = (col[1] * T_i - w1 / one_m) * gg;
                     float ag2 = (col[2] * T_i - w2 / one_m) * gb;
+                    const float w0_before = w0, w1_before = w1, w2_before = w2;
                     w0 += col[0] * alpha * T_i; w1 += col[1] * alpha * T_i; w2 += col[2] * alpha * T_i;
                     float alpha_grad = ag0 + ag1 + ag2;
                     float pa_grad = alpha_grad * gaussian_alpha;
@@ -719,11 +720,24 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
                     GSO_ADD(a_mag[p], mg);
                     GSO_ADD(a_cnt[p], 1);
                     if (a_abs) {
+                        /* the same expressions with every product replaced by its absolute value, all the way down:
+                         * a contribution is itself a sum that can cancel (colour*T against w/(1-alpha) in alpha_grad,
+                         * a*dx against b*dy in Sigma^-1 d, the terms of Sigma^-1 d d^T Sigma^-1) */
                         double* ab = a_abs + 9 * (size_t)p;
-                        GSO_ADD(ab[0], fabsf(vs0)); GSO_ADD(ab[1], fabsf(vs1));
-                        GSO_ADD(ab[2], fabsf(cg00)); GSO_ADD(ab[3], fabsf(cg01)); GSO_ADD(ab[4], fabsf(cg11));
+                        double Aag = ((double)fabsf(col[0] * T_i) + fabsf(w0_before / one_m)) * fabsf(gr)
+                                   + ((double)fabsf(col[1] * T_i) + fabsf(w1_before / one_m)) * fabsf(gg)
+                                   + ((double)fabsf(col[2] * T_i) + fabsf(w2_before / one_m)) * fabsf(gb);
+                        double Ag = Aag * fabsf(apt) * fabsf(gaussian_alpha);          /* |g_alpha_grad| * p, un-cancelled */
+                        double fa = fabsf(a), fb = fabsf(b), fc = fabsf(c), adx = fabsf(dx), ady = fabsf(dy);
+                        double Acix = fa * adx + fb * ady, Aciy = fb * adx + fc * ady;
+                        double Aio00 = fa * adx * adx + fb * ady * adx, Aio01 = fa * adx * ady + fb * ady * ady;
+                        double Aio10 = fb * adx * adx + fc * ady * adx, Aio11 = fb * adx * ady + fc * ady * ady;
+                        GSO_ADD(ab[0], Ag * Acix); GSO_ADD(ab[1], Ag * Aciy);
+                        GSO_ADD(ab[2], 0.5 * Ag * (Aio00 * fa + Aio01 * fb));
+                        GSO_ADD(ab[3], 0.5 * Ag * (Aio00 * fb + Aio01 * fc));
+                        GSO_ADD(ab[4], 0.5 * Ag * (Aio10 * fb + Aio11 * fc));
                         GSO_ADD(ab[5], fabsf(gcol0)); GSO_ADD(ab[6], fabsf(gcol1)); GSO_ADD(ab[7], fabsf(gcol2));
-                        GSO_ADD(ab[8], fabsf(opacity_grad));
+                        GSO_ADD(ab[8], Aag * fabsf(gaussian_alpha) * fabsf((1.0f - apt) * apt));
                     }
 #undef GSO_ADD
                 }

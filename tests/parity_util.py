@@ -81,15 +81,18 @@ def rel_err(a, ref):
 
 
 GRAD_TOL = 1e-4          # tensor-level: max |a - ref| / max |ref| per column group
-# Per-element bar: |a - ref| <= ELEM_RTOL * |ref| + ELEM_FLOOR * S, S = the oracle's "summed" magnitude of the element
-# (sum of |every loop-1 contribution| through |the loop-2 Jacobian| and the grad factor, gso_backward_ex).  An
-# element is a float sum of up to ~1e4 signed terms; what f32 can promise is relative to what was added up, not to
-# what is left after cancellation (the reference itself adds the same terms with unordered f32 atomics, RAST:674-696).
-# The floor covers, per term: hardware-exp alpha (2e-6), the T recurrence drifting by an ulp per step over a pixel's
-# list (~6e-7 rms over 100 steps), and f32 summation of n <= 1e4 terms (sqrt(n) * 2^-24 ~ 6e-6): 1e-5 in all, a tenth of
-# the 1e-4 bar.  An element whose terms do not cancel (S ~ |ref|) is therefore held to 1.1e-4 relative.
-ELEM_RTOL = 1e-4
-ELEM_FLOOR = 1e-5
+# Per-element bar: |a - ref| <= ELEM_RTOL * |ref| + ELEM_FLOOR * S.  S is the oracle's "summed" magnitude of the
+# element (gso_backward_ex): the reference's own expressions for the element with every product replaced by its
+# absolute value all the way down -- sum over the loop-1 contributions (RAST:674-696) of the un-cancelled size of each
+# contribution (colour*T against w/(1-alpha) in d alpha, a*dx against b*dy in Sigma^-1 d, the terms of Sigma^-1 d d^T Sigma^-1),
+# through |loop-2 Jacobian| and the grad factor.  That is the quantity a float evaluation can be accurate relative to
+# (the componentwise forward-error bound): an element is a sum of up to ~1e4 signed terms, each itself a difference,
+# and the reference adds them with unordered f32 atomics.  The floor covers, per product: hardware-exp alpha (2e-6
+# relative), the T recurrence drifting by an ulp per step over a pixel's list (~6e-7 rms over 100 steps), and f32
+# summation of n <= 1e4 terms (sqrt(n) * 2^-24 ~ 6e-6 worst case, measured 1.7e-6): 5e-6 in all.  Measured at
+# BASELINE configs 2 and 3 (profiles/r02_parity_margins.json): no element uses more than a third of this bar.
+ELEM_RTOL = 2e-5         # five times tighter than the 1e-4 of BASELINE.md
+ELEM_FLOOR = 5e-6
 GROUPS = [(0, 4, "q"), (4, 7, "s"), (7, 8, "opacity"), (8, 56, "sh")]
 
 
@@ -122,15 +125,15 @@ def backward_margins(gp, gf, b):
     return out
 
 
-def assert_backward_parity(module, inp, g_image, f, band, extras=None, cfg=None):
+def assert_backward_parity(module, inp, g_image, f, band, extras=None, cfg=None, tensor_tol=GRAD_TOL):
     b = oracle.backward(f, g_image, band, cfg, want_summed=True)
     gp = inp.point_cloud.grad.cpu().numpy()
     gf = inp.point_cloud_features.grad.cpu().numpy()
-    assert rel_err(gp, b["grad_pointcloud"]) < GRAD_TOL, ("xyz", rel_err(gp, b["grad_pointcloud"]))
+    assert rel_err(gp, b["grad_pointcloud"]) < tensor_tol, ("xyz", rel_err(gp, b["grad_pointcloud"]))
     for lo, hi, name in GROUPS:
         e = rel_err(gf[:, lo:hi], b["grad_pointcloud_features"][:, lo:hi])
-        assert e < GRAD_TOL, (name, e)
-    # every element on its own: within 1e-4 of its value plus 1e-5 of the magnitude that was summed to produce it;
+        assert e < tensor_tol, (name, e)
+    # every element on its own: within ELEM_RTOL of its value plus ELEM_FLOOR of the magnitude summed to produce it;
     # where nothing was summed (rows outside the frustum, masked SH bands, pixels-free splats) exactly zero
     margins = backward_margins(gp, gf, b)
     for name, m in margins.items():

@@ -424,11 +424,20 @@ def test_backward_through_depth_only_gives_zero_gradients(P):
 @pytest.mark.parametrize("seed", [60163, 60266])
 def test_soak_seeds_with_ill_conditioned_splats(P, seed):
     """The two scenes of round 1's parity soak (tools/parity_soak.py; narrow, tall images full of huge anisotropic
-    splats) where the HIP kernel -- then a closed form for dL/dM -- and the oracle -- the reference's 4x9 . 9x9 . 9x4
-    product order, GP3D:270-330, in f32 -- were 1.09e-4 / 1.14e-4 of the tensor maximum apart on the scale gradient, and a
-    float64 autograd restatement had to arbitrate.  k_bwd_points now follows the reference's product order too, so the
-    comparison that counts (HIP vs oracle) passes on its own; the float64 numbers are recorded beside it to show what the
-    reference's f32 operation order costs on such splats: both f32 results sit ~1e-4 from float64, together."""
+    splats; 2 of 340 such cases) where HIP and oracle are 1.1e-4 of the tensor maximum apart on the scale gradient --
+    over the tensor-level bar.  All three numbers are produced here: HIP vs oracle, HIP vs a float64 autograd
+    restatement (tests/torch_ref.py), oracle vs float64.
+
+    Cause (found with the per-element metric, not the one round 1 named: k_bwd_points now follows the reference's
+    GP3D:270-330 product order like the oracle and the gap did not move): the reference forms d p / d Sigma' per
+    contribution as 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two f32 matrix products (UTIL:343-345), the oracle follows it,
+    and for a long thin conic a*dx and b*dy cancel in Sigma^-1 d, so the products carry an absolute error of
+    2^-24 (|a dx| + |b dy|)^2 against a value (a dx + b dy)^2 that is orders smaller.  k_blend_bwd_tile forms the same
+    quantity as v v^T with v = Sigma^-1 d (three fused multiply-adds instead of 24 operations in the kernel that
+    dominates the frame), which does not lose those digits: it agrees with float64 ten times better than the oracle
+    does.  Mirroring the reference's rounding there would cost ~40 % of the dominant kernel to be less accurate.
+    The per-element bar, whose floor is built from the un-cancelled magnitudes of exactly those products, holds against
+    the ORACLE in both scenes without any arbitration; the tensor-level figure is allowed 2e-4 here and nowhere else."""
     import json
     import os
     c = P.soak_case(seed)
@@ -448,7 +457,8 @@ def test_soak_seeds_with_ill_conditioned_splats(P, seed):
     target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
     g = 2.0 * (image.detach() - target)
     image.backward(g)
-    b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3, None, ocfg)      # HIP vs oracle: tensor-level AND per element
+    # HIP vs oracle: every element under the per-element bar; tensor level within 2e-4 (see above)
+    b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3, None, ocfg, tensor_tol=2e-4)
     ref_pc, ref_ft = P.float64_autograd_gradients(s, q, t, f, feat_after, g.cpu().numpy())
     gp, gf = inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()
     op, of = b["grad_pointcloud"], b["grad_pointcloud_features"]
@@ -457,12 +467,12 @@ def test_soak_seeds_with_ill_conditioned_splats(P, seed):
     # the reference's backward with t_pointcloud_camera (RAST:731-732), which differ for the non-unit pose quaternion used here
     for name, a_hip, a_orc, a_f64 in [("xyz", gp, op, ref_pc), ("q", gf[:, 0:4], of[:, 0:4], ref_ft[:, 0:4]),
                                       ("s", gf[:, 4:7], of[:, 4:7], ref_ft[:, 4:7]), ("opacity", gf[:, 7:8], of[:, 7:8], ref_ft[:, 7:8])]:
-        report[name] = {"hip_vs_oracle": P.rel_err(a_hip, a_orc), "hip_vs_float64": P.rel_err(a_hip, a_f64),
-                        "oracle_vs_float64": P.rel_err(a_orc, a_f64)}
-        assert report[name]["hip_vs_oracle"] < 1e-5, (name, report[name])          # same operation order: far inside the 1e-4 bar
-        # what f32 in the reference's product order costs here; HIP and oracle pay it together
-        assert report[name]["hip_vs_float64"] < 3e-4 and report[name]["oracle_vs_float64"] < 3e-4, (name, report[name])
-    report["per_element_bar_use"] = {k: v["bar_use_max"] for k, v in b["margins"].items()}
+        r = {"hip_vs_oracle": P.rel_err(a_hip, a_orc), "hip_vs_float64": P.rel_err(a_hip, a_f64), "oracle_vs_float64": P.rel_err(a_orc, a_f64)}
+        report[name] = r
+        assert r["hip_vs_float64"] < 2e-5, (name, r)                   # the HIP result against exact arithmetic
+        assert r["oracle_vs_float64"] < 2e-4, (name, r)                # the reference's f32 operation order against it
+    assert report["s"]["hip_vs_oracle"] > 1e-4 > 5 * report["s"]["hip_vs_float64"]      # this IS the oracle-limited case
+    report["per_element_bar_use_vs_oracle"] = {k: v["bar_use_max"] for k, v in b["margins"].items()}
     os.makedirs(os.path.join(P.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(P.ROOT, "gpurun_out", f"soak_seed_{seed}.json"), "w") as fh:
         json.dump(report, fh, indent=1)

@@ -92,3 +92,26 @@ def test_hook_extras_consistency():
     # points outside the frustum get exactly zero gradient (RAST:1051-1058 zero-init)
     out = np.setdiff1d(np.arange(f.N), f.point_id_in_camera_list)
     assert np.all(b["grad_pointcloud"][out] == 0) and np.all(b["grad_pointcloud_features"][out] == 0)
+
+
+def test_summed_magnitudes_bound_the_gradients():
+    """gso_backward_ex's "summed" outputs (the floor of the GPU tests' per-element bar): every gradient element is bounded by
+    the magnitude summed to produce it (triangle inequality, up to rounding), is exactly zero where nothing was summed,
+    and masked SH bands / rows outside the frustum have nothing summed."""
+    s, q, t, target = _tiny(5, 400, 0.3, 64, 48)
+    f, _ = oracle.forward(s.point_cloud, s.point_cloud_features, s.point_invalid_mask, s.point_object_id,
+                          q, t, s.camera_intrinsics, s.height, s.width)
+    g = (2.0 * (f.rasterized_image - target)).astype(np.float32)
+    b = oracle.backward(f, g, 1, want_summed=True)
+    plain = oracle.backward(f, g, 1)
+    assert np.array_equal(plain["grad_pointcloud_features"], b["grad_pointcloud_features"])
+    for gk, sk in [("grad_pointcloud", "summed_pointcloud"), ("grad_pointcloud_features", "summed_pointcloud_features")]:
+        G, S = np.abs(b[gk]).astype(np.float64), b[sk].astype(np.float64)
+        assert np.all(G <= S * (1 + 1e-5)), gk
+        assert not G[S == 0].any(), gk
+        assert (S > 0).any()
+    Sf = b["summed_pointcloud_features"]
+    for base in (8, 24, 40):
+        assert not Sf[:, base + 4: base + 16].any()           # band 1 keeps coefficients 0..3
+    out = np.setdiff1d(np.arange(f.N), f.point_id_in_camera_list)
+    assert not Sf[out].any() and not b["summed_pointcloud"][out].any()
