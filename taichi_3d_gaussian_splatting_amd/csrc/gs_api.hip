@@ -50,11 +50,11 @@ struct DevBuf {
 
 // What RAST:998-1019 saves for backward, in this library's layouts (DESIGN.md "HBM layout").
 struct FrameBufs {
-    DevBuf mask, ids, cam_index, PA, PB, PC, PD, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
+    DevBuf mask, ids, cam_index, rec, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
     bool in_use = false;
     void release(int64_t* total)
     {
-        DevBuf* all[] = { &mask, &ids, &cam_index, &PA, &PB, &PC, &PD, &box, &ntiles, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
+        DevBuf* all[] = { &mask, &ids, &cam_index, &rec, &box, &ntiles, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
                           &tile_start, &pose, &tile_order };
         for (DevBuf* b : all) b->release(total);
     }
@@ -270,7 +270,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     const size_t Np = (size_t)(N > 0 ? N : 1);
 
     ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
-    ENSURE(B.PA, 16 * Np); ENSURE(B.PB, 16 * Np); ENSURE(B.PC, 16 * Np); ENSURE(B.PD, 16 * Np);
+    ENSURE(B.rec, 64 * Np);
     ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.offsets, 4 * Np);
     ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared by ONE memset
     ENSURE(B.tile_order, 4 * (size_t)T);
@@ -287,7 +287,11 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     pa.pose = B.pose.as<GsPose>(); pa.mask = B.mask.as<int8_t>();
     pa.block_counts = c->block_counts.as<int32_t>(); pa.block_offsets = c->block_offsets.as<int32_t>();
     pa.ids = B.ids.as<int32_t>(); pa.cam_index = B.cam_index.as<int32_t>();
-    pa.PA = B.PA.as<float4>(); pa.PB = B.PB.as<float4>(); pa.PC = B.PC.as<float4>(); pa.PD = B.PD.as<float4>();
+    {   // GS_RS == 4: one 64-byte row per point; GS_RS == 1: four planes of Np records
+        float4* rec = B.rec.as<float4>();
+        const size_t plane = GS_RS == 4 ? 1 : Np;
+        pa.PA = rec; pa.PB = rec + plane; pa.PC = rec + 2 * plane; pa.PD = rec + 3 * plane;
+    }
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
@@ -406,7 +410,12 @@ extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_
     GsExportArgs a{};
     a.what = (int)what; a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = (uint32_t)f->info.n_keys;
     a.T = f->info.n_tiles; a.depth_bits = f->depth_bits; a.key64 = f->key64;
-    a.ids = B.ids.as<int32_t>(); a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
+    a.ids = B.ids.as<int32_t>();
+    {
+        const float4* rec = B.rec.as<float4>();
+        const size_t plane = GS_RS == 4 ? 1 : (size_t)(f->info.n_points > 0 ? f->info.n_points : 1);
+        a.PA = rec; a.PB = rec + plane; a.PC = rec + 2 * plane; a.PD = rec + 3 * plane;
+    }
     a.ntiles = B.ntiles.as<int32_t>(); a.offsets = B.offsets.as<uint32_t>();
     a.keys_sorted = f->keys_sorted; a.vals_sorted = f->vals_sorted;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.mask = B.mask.as<int8_t>();
@@ -461,7 +470,11 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.tiles_x = (a.W + GS_TILE - 1) / GS_TILE;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.vals_sorted = f->vals_sorted;
     a.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)f->info.n_tiles; a.tile_order = B.tile_order.as<int32_t>();
-    a.PA = B.PA.as<float4>(); a.PB = B.PB.as<float4>(); a.PC = B.PC.as<float4>(); a.PD = B.PD.as<float4>();
+    {
+        const float4* rec = B.rec.as<float4>();
+        const size_t plane = GS_RS == 4 ? 1 : (size_t)(f->info.n_points > 0 ? f->info.n_points : 1);
+        a.PA = rec; a.PB = rec + plane; a.PC = rec + 2 * plane; a.PD = rec + 3 * plane;
+    }
     a.box = B.box.as<ushort4>(); a.offsets = B.offsets.as<uint32_t>(); a.ntiles = B.ntiles.as<int32_t>();
     a.ids = B.ids.as<int32_t>(); a.cam_index = B.cam_index.as<int32_t>();
     a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;

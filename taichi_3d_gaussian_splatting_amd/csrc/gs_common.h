@@ -23,6 +23,15 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #else
 #define GS_STAT(i, n) do { } while (0)
 #endif
+// Projected splat records: four float4 per in-camera point -- A {u, v, conic a, conic b}, B {conic c, rescale, opacity, depth},
+// C {r, g, b, log-domain alpha cut}, D {x, y, z in camera, radius} -- kept as ONE 64-byte row per point (GS_RS = 4: the
+// pointers PA..PD are rec, rec+1, rec+2, rec+3), so that the blend kernels' gather by sorted index touches one
+// 64-byte segment per splat instead of three cache lines, and so that a shard's records are one contiguous
+// (M,16) float array for the Gaussian-parallel exchange.  GS_RS = 1 selects four separate planes (A/B measurement).
+#ifndef GS_RS
+#define GS_RS 4
+#endif
+#define GS_REC(ptr, i) (ptr)[(size_t)(i) * GS_RS]
 #define GS_BOUNDARY_TILES 3          // reference RAST:26
 #define GS_ALPHA_EPS 0.00392156862745098f   // 1./255. (RAST:451, RAST:634)
 #define GS_ALPHA_MAX 0.99f           // RAST:453

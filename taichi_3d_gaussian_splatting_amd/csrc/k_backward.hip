@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
         const bool valid = i < hi;
         const int p = valid ? sorted_vals[i] : 0;
         {
-            const float4 A = PA[p], B = PB[p], C = PC[p];
+            const float4 A = GS_REC(PA, p), B = GS_REC(PB, p), C = GS_REC(PC, p);
             const CullSplat cs = gs_cull_prepare(A, B, C);
             unsigned long long mq[NQ];
             unsigned long long U = 0ull;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
             s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
         }
         {   // the per-splat factors k_blend_bwd_tile left out (see there): opacity, 0.5, (1 - opacity) * opacity
-            const float apt = PB[m].z;
+            const float apt = GS_REC(PB, m).z;
             s[0] *= apt; s[1] *= apt; s[9] *= apt;
             const float h = 0.5f * apt;
             s[2] *= h; s[3] *= h; s[4] *= h;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
             gt[j] = guv0 * j0 + guv1 * j1;
         }
         // ---- d Sigma' / d(q, s), GP3D:237-331, contracted with (g00 g01; g01 g11) ----
-        const float4 pd = PD[m];                                        // translation_camera, RAST:737-738
+        const float4 pd = GS_REC(PD, m);                                        // translation_camera, RAST:737-738
         const float fx = Km[0], fy = Km[4];
         float J[6] = { fx / pd.z, 0.0f, -(fx * pd.x) / (pd.z * pd.z), 0.0f, fy / pd.z, -(fy * pd.y) / (pd.z * pd.z) };
         float U[6];
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         if (hook_mag) hook_mag[m] = s[9];
         if (hook_ids) hook_ids[m] = (int32_t)n;                         // RAST:1129, 1136-1139
         if (hook_ntiles) hook_ntiles[m] = ntiles[m];
-        if (hook_depth) hook_depth[m] = PB[m].w;
-        if (hook_uv) { const float4 pa = PA[m]; hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
+        if (hook_depth) hook_depth[m] = GS_REC(PB, m).w;
+        if (hook_uv) { const float4 pa = GS_REC(PA, m); hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
         if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
             const int32_t npix = (int32_t)(s[10] + 0.5f);
             c_num_in_camera[n] += 1;

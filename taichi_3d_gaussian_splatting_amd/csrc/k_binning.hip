@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
     if (valid) {
         offsets[idx] = off;
         bx = boxes[idx];
-        depth_code = (KeyT)(uint32_t)(int)(PB[idx].w * depth_scale);         // RAST:159-160
+        depth_code = (KeyT)(uint32_t)(int)(GS_REC(PB, idx).w * depth_scale);         // RAST:159-160
     }
     const int du = (int)bx.y - (int)bx.x, dv = (int)bx.w - (int)bx.z;
     // points with few tiles: a lane lists its pairs in LDS, then the wave writes all of them out together so that

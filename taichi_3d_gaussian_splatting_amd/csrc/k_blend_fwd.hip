@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         const int i = base + lane;
         const bool valid = i < end;
         const int p = valid ? sorted_vals[i] : 0;
-        float4 A = PA[p], B = PB[p], C = PC[p];
+        float4 A = GS_REC(PA, p), B = GS_REC(PB, p), C = GS_REC(PC, p);
         bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), rx0, ry0);
         unsigned long long mask = gs_ballot(keep);
         GS_STAT(0, 1); GS_STAT(1, __popcll(mask));

@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         // whenever e < cut (margins are applied where it is used).  Not an index-determining value.
         float ra = rescale * alpha;
         float cut = ra > 0.0f ? __logf(GS_ALPHA_EPS / ra) : (ra == 0.0f ? 3.0e38f : -3.0e38f);
-        PA[idx] = make_float4(uv[0], uv[1], conic_a, conic_b);
-        PB[idx] = make_float4(conic_c, rescale, alpha, pcam[2]);
-        PC[idx] = make_float4(col[0], col[1], col[2], cut);
-        PD[idx] = make_float4(pcam[0], pcam[1], pcam[2], radii);
+        GS_REC(PA, idx) = make_float4(uv[0], uv[1], conic_a, conic_b);
+        GS_REC(PB, idx) = make_float4(conic_c, rescale, alpha, pcam[2]);
+        GS_REC(PC, idx) = make_float4(col[0], col[1], col[2], cut);
+        GS_REC(PD, idx) = make_float4(pcam[0], pcam[1], pcam[2], radii);
         boxes[idx] = make_ushort4((unsigned short)box[0], (unsigned short)box[1], (unsigned short)box[2], (unsigned short)box[3]);
         ntiles[idx] = count;
     }

@@ -122,3 +122,17 @@ def preallocate(point_cloud: np.ndarray, features: np.ndarray, max_num_points_ra
     mask = np.ones(total, np.int8)
     mask[:n] = 0
     return pc, ft, mask, np.zeros(total, np.int32)
+
+
+def merge_scenes(scenes):
+    """Several loaded scenes as ONE point set with one pose row per scene, the way the reference's visualiser feeds the
+    operator (visualizer.py:292-323): rows concatenated in order, point_object_id = index of the source scene.
+    `scenes` is a list of (point_cloud, point_cloud_features) or (point_cloud, features, point_invalid_mask).
+    Returns (point_cloud, features, point_invalid_mask i8, point_object_id i32)."""
+    pcs, fts, masks, objs = [], [], [], []
+    for k, sc in enumerate(scenes):
+        pc, ft = np.asarray(sc[0], np.float32), np.asarray(sc[1], np.float32)
+        mask = np.zeros(pc.shape[0], np.int8) if len(sc) < 3 or sc[2] is None else np.asarray(sc[2], np.int8)
+        pcs.append(pc); fts.append(ft); masks.append(mask); objs.append(np.full(pc.shape[0], k, np.int32))
+    return (np.ascontiguousarray(np.concatenate(pcs)), np.ascontiguousarray(np.concatenate(fts)),
+            np.ascontiguousarray(np.concatenate(masks)), np.ascontiguousarray(np.concatenate(objs)))

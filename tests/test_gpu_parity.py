@@ -242,6 +242,24 @@ def test_cfg5_inference_2e6_forward_parity_and_properties(P):
     assert float(image.min()) >= 0.0 and float(image.max()) <= 1.0 + 1e-5
 
 
+def test_cfg5_inference_2e6_rgb_only(P):
+    """BASELINE config 5 with rgb_only=True (RAST:409-410, 464-484: only the image is produced), the form the reference's
+    inference benchmark can run (benchmark/inference_benchmark.py): the image equals the all-outputs image bit for bit
+    (same blend arithmetic, three stores fewer) and the oracle's within the image bar; the binning is identical."""
+    s = synth(**CONFIGS["cfg5_infer2e6"])
+    q, t = view_pose()
+    f, feat_after = P.run_oracle(s, q, t)
+    imgs = {}
+    for rgb_only in (True, False):
+        module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig(rgb_only=rgb_only))
+        inp = P.make_input(s, q, t, requires_grad=False)
+        with torch.no_grad():
+            outs = module(inp)
+        P.assert_forward_parity(module, inp, outs, f, feat_after, rgb_only=rgb_only)
+        imgs[rgb_only] = outs[0].cpu().numpy()
+    assert np.array_equal(imgs[True].view(np.uint32), imgs[False].view(np.uint32))
+
+
 def test_several_frames_in_flight_and_arena_is_stable(P):
     """Two forwards, then their backwards in reverse order (frames pin separate buffer sets); afterwards the
     context allocates nothing more for repeated steps (grow-only arena, no hipMalloc in steady state)."""

@@ -58,3 +58,14 @@ def test_preallocation_rows():
     assert pc2.shape == (25, 3) and ft2.shape == (25, 56) and mask.dtype == np.int8 and obj.dtype == np.int32
     assert mask[:10].sum() == 0 and mask[10:].all() and not pc2[10:].any()
     assert scene_io.preallocate(pc, ft, None)[0].shape == (10, 3)
+
+
+def test_merge_scenes_assigns_object_ids_in_order(scene):
+    pc, ft = scene
+    mask = np.zeros(500, np.int8)
+    mask[3] = 1
+    mpc, mft, minv, mobj = scene_io.merge_scenes([(pc, ft), (pc[:100] + 1.0, ft[:100], mask[:100])])   # visualizer.py:292-323
+    assert mpc.shape == (600, 3) and mft.shape == (600, 56)
+    assert np.array_equal(mobj, np.concatenate([np.zeros(500, np.int32), np.ones(100, np.int32)]))
+    assert minv.sum() == 1 and minv[503] == 1
+    assert np.array_equal(mpc[500:], pc[:100] + 1.0)
