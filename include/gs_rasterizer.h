@@ -11,10 +11,16 @@
  * return 0 on success and a negative gs_status otherwise, never throw, and set a
  * thread-local message readable through gs_last_error().
  *
- * Threading: a gs_ctx may be used from any host thread, one call at a time
- * (PyTorch calls forward on the main thread and backward on an autograd worker).
- * All work of one ctx must be issued on one HIP stream at a time (buffers are
- * recycled in stream order).
+ * Threading: a gs_ctx may be used from any host thread; calls on one ctx are
+ * serialised by a mutex (PyTorch calls forward on the main thread and backward on an
+ * autograd worker).  Streams: the scratch buffers of a ctx are recycled in stream order.
+ * When a call arrives on a different stream than the previous call of the same ctx, the
+ * library makes the new stream wait (hipStreamWaitEvent, no host block) for everything the
+ * ctx has issued on the old one, so switching streams is safe; use one ctx per stream for
+ * work that is meant to overlap.
+ *
+ * Frame handles (gs_frame*) are opaque tickets, never dereferenced by the caller and
+ * checked on every use: a released, recycled or foreign handle gives GS_ERR_STATE.
  */
 #ifndef GS_RASTERIZER_H
 #define GS_RASTERIZER_H
@@ -24,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -33,7 +39,7 @@ typedef enum gs_status {
     GS_ERR_INVALID_ARGUMENT = -1,   /* the reference's Python asserts / Taichi TypeErrors (RAST:1193-1194) */
     GS_ERR_HIP = -2,                /* a HIP runtime call failed; message carries hipGetErrorString */
     GS_ERR_OUT_OF_MEMORY = -3,
-    GS_ERR_STATE = -4               /* e.g. backward on a frame that was not kept */
+    GS_ERR_STATE = -4               /* e.g. backward on a frame that was not kept, or a stale frame handle */
 } gs_status;
 
 typedef struct gs_ctx gs_ctx;       /* one per operator instance per device (RAST:819-826) */
@@ -60,7 +66,8 @@ typedef struct gs_scene {
     const float*   point_cloud;             /* device (N,3) f32 */
     float*         point_cloud_features;    /* device (N,56) f32; [:,0:4] is normalised IN PLACE (RAST:264-266) */
     const int8_t*  point_invalid_mask;      /* device (N) i8, 1 = skip */
-    const int32_t* point_object_id;         /* device (N) i32 in [0, n_objects) */
+    const int32_t* point_object_id;         /* device (N) i32 in [0, n_objects); a valid row with an id outside that range is
+                                               treated as not in camera and gs_forward returns GS_ERR_INVALID_ARGUMENT */
     int64_t        n_points;                /* N */
 } gs_scene;
 
@@ -94,7 +101,13 @@ typedef struct gs_frame_info {
     int32_t camera_height, camera_width;
     int32_t sort_key_bits;          /* significant bits actually radix-sorted */
     int32_t kept_for_backward;
+    int32_t stages;                 /* GS_STAGE_PROJECT | GS_STAGE_RASTER: which halves of the path the frame holds */
 } gs_frame_info;
+
+#define GS_STAGE_PROJECT 1          /* filter + compaction + projection (gs_forward, gs_project_shard) */
+#define GS_STAGE_RASTER  2          /* binning + sort + blend (gs_forward, gs_forward_projected) */
+#define GS_RECORD_FLOATS 16         /* floats per projected splat record */
+#define GS_SPLAT_SUM_FLOATS 12      /* floats per per-splat backward sum row */
 
 /* Optional: the six per-point accumulators of the adaptive density controller
  * (GaussianPointAdaptiveController.py:114-127), updated IN PLACE (+=) for every in-camera point exactly as
@@ -171,11 +184,11 @@ int gs_destroy(gs_ctx* ctx);
 int gs_forward(gs_ctx* ctx, const gs_scene* scene, const gs_camera* camera, const gs_config* config,
                const gs_forward_out* out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
 
-int gs_frame_get_info(const gs_frame* frame, gs_frame_info* info);
+int gs_frame_get_info(gs_ctx* ctx, const gs_frame* frame, gs_frame_info* info);
 
-/* Element count of an export (so the caller can size dst). */
-int64_t gs_frame_export_count(const gs_frame* frame, gs_export what);
-int gs_frame_export(const gs_frame* frame, gs_export what, void* dst_device, gs_stream stream);
+/* Element count of an export (so the caller can size dst); -1 for a stale handle or an export the frame does not hold. */
+int64_t gs_frame_export_count(gs_ctx* ctx, const gs_frame* frame, gs_export what);
+int gs_frame_export(gs_ctx* ctx, const gs_frame* frame, gs_export what, void* dst_device, gs_stream stream);
 
 /* Replaces _module_function.backward, RAST:1025-1163 (kernel RAST:488-772 and the
  * torch post-processing RAST:1102-1140).  pixel_accumulated_alpha and
@@ -186,7 +199,46 @@ int gs_backward(gs_ctx* ctx, gs_frame* frame, const gs_scene* scene, const gs_ca
                 const float* pixel_accumulated_alpha, const int32_t* pixel_offset_of_last_effective_point,
                 int32_t color_max_sh_band, const gs_backward_out* out, gs_stream stream);
 
+/* May be called any number of times between forward and release (backward(retain_graph=True) in PyTorch terms). */
+
 int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
+
+/* ---- the same path cut at the projected records and at the per-splat sums -----------------
+ * For Gaussian-parallel multi-GPU rendering: the rank that OWNS a shard of the Gaussians runs the per-point halves
+ * (gs_project_shard, gs_backward_shard), the rank that RENDERS a view runs the per-pixel halves (gs_forward_projected,
+ * gs_backward_projected); between them travel the projected splat records (16 floats per in-camera point) and the
+ * per-splat backward sums (12 floats), instead of 59 gradient floats per Gaussian of the scene.  Chained on one GPU
+ * the four calls give bit for bit what gs_forward + gs_backward give.  The reference has no counterpart (it is
+ * single-GPU); the cut points are its own intermediate tensors: the records are RAST:873-911's per-point arrays, the
+ * sums are the accumulators of RAST:674-696 (grad_uv, cov buffer, colour buffer, opacity, magnitude, pixel count).
+ *
+ * Record layout (GS_RECORD_FLOATS): u v conic_a conic_b | conic_c rescale opacity depth | r g b alpha_cut | x y z(camera) radius.
+ * Sum row layout (GS_SPLAT_SUM_FLOATS): d uv (2) | d cov xx xy yy (3) | d colour (3) | d opacity | sum |d uv| | pixel count (i32 bits) | 0;
+ * rows are pre-factor sums exactly as k_blend_bwd_tile leaves them (opacity, 0.5 and (1-o)o are applied by the shard half). */
+
+/* Per-point half of the forward for a shard of the scene: frustum filter, compaction (ascending ids), projection.
+ * records_out: device (capacity >= scene->n_points rows, 16 floats each), receives M rows in ascending point id;
+ * ids_out: device (n_points) i32 or NULL, receives the M in-camera point ids.  M = n_points_in_camera of the frame. */
+int gs_project_shard(gs_ctx* ctx, const gs_scene* shard, const gs_camera* camera, const gs_config* config,
+                     float* records_out, int32_t* ids_out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
+
+/* Per-pixel half of the forward from m records (any concatenation of shards' records; ties in the depth sort are
+ * broken by position in this array, so concatenating shards in ascending point-id order reproduces gs_forward).
+ * Only camera_height / camera_width of *camera are read. */
+int gs_forward_projected(gs_ctx* ctx, const float* records, int64_t m, const gs_camera* camera, const gs_config* config,
+                         const gs_forward_out* out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
+
+/* Per-pixel half of the backward: blend backward + per-splat sums.  splat_sums_out: device (m, 12) f32, every row
+ * written; magnitude_grad_viewspace_on_image: device (H,W,2) or NULL. */
+int gs_backward_projected(gs_ctx* ctx, gs_frame* frame, const float* grad_rasterized_image,
+                          const float* pixel_accumulated_alpha, const int32_t* pixel_offset_of_last_effective_point,
+                          float* splat_sums_out, float* magnitude_grad_viewspace_on_image, gs_stream stream);
+
+/* Per-point half of the backward for the shard a gs_project_shard frame came from: Jacobian chain, band masks, grad
+ * factors, hook payload (as gs_backward; out->magnitude_grad_viewspace_on_image is not written here).
+ * splat_sums: device (M, 12), the rows of this shard's in-camera points in the order of records_out. */
+int gs_backward_shard(gs_ctx* ctx, gs_frame* frame, const gs_scene* shard, const gs_camera* camera, const gs_config* config,
+                      const float* splat_sums, int32_t color_max_sh_band, const gs_backward_out* out, gs_stream stream);
 
 /* ---- the step either side of the operator in the reference's training loop ---------------- */
 

@@ -49,14 +49,15 @@ def _require(t: torch.Tensor, name: str, dtype, shape_tail, device=None):
 
 
 class _Frame:
-    """Owner of a gs_frame handle: what ctx.save_for_backward keeps in the reference (RAST:998-1021)."""
+    """Owner of a gs_frame ticket: what ctx.save_for_backward keeps in the reference (RAST:998-1021).  Holds the
+    context alive (the ticket is meaningless without it) and gives the ticket back when it dies."""
 
-    def __init__(self, ctx_handle, handle, device):
-        self._ctx, self._h, self.device = ctx_handle, handle, device
+    def __init__(self, context: "_native.Context", handle, device, owned=True):
+        self._context, self._h, self.device, self._owned = context, handle, device, owned
         info = _native.GsFrameInfo()
-        _native.check(_native.lib().gs_frame_get_info(self._h, C.byref(info)), "gs_frame_get_info")
+        _native.check(_native.lib().gs_frame_get_info(context.handle, self._h, C.byref(info)), "gs_frame_get_info")
         self.n_points, self.n_points_in_camera, self.n_keys = info.n_points, info.n_points_in_camera, info.n_keys
-        self.n_tiles, self.sort_key_bits = info.n_tiles, info.sort_key_bits
+        self.n_tiles, self.sort_key_bits, self.stages = info.n_tiles, info.sort_key_bits, info.stages
 
     @property
     def handle(self):
@@ -67,21 +68,24 @@ class _Frame:
     def export(self, name: str) -> torch.Tensor:
         eid, dtype, tail = _native.EXPORTS[name]
         L = _native.lib()
-        n = L.gs_frame_export_count(self.handle, eid)
+        n = L.gs_frame_export_count(self._context.handle, self.handle, eid)
         if n < 0:
-            raise RuntimeError(f"gs_frame_export_count({name}) failed")
+            raise RuntimeError(f"gs_frame_export_count({name}) failed: the frame is no longer live or does not hold that stage")
         rows = n
         for d in tail:
             rows //= d
         out = torch.empty((rows, *tail), dtype=_TORCH_DTYPES[dtype], device=self.device)
         if n > 0:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            _native.check(L.gs_frame_export(self.handle, eid, _ptr(out), C.c_void_p(stream)), f"gs_frame_export({name})")
+            _native.check(L.gs_frame_export(self._context.handle, self.handle, eid, _ptr(out), C.c_void_p(stream)), f"gs_frame_export({name})")
         return out
 
     def release(self):
+        """Hands the ticket back.  Transient frames (forward without gradient tracking) belong to the context and are
+        recycled by its next forward; their ticket then simply stops resolving."""
         if self._h is not None:
-            _native.lib().gs_frame_release(self._ctx, self._h)
+            if self._owned and self._context.handle:
+                _native.lib().gs_frame_release(self._context.handle, self._h)
             self._h = None
 
     def __del__(self):
@@ -141,7 +145,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.config = config
         self._hook = backward_valid_point_hook
         self.controller_accumulators = controller_accumulators
-        self._ctxs = {}                     # device index -> gs_ctx*
+        self._ctxs = {}                     # device index -> _native.Context (owner of the gs_ctx)
         self.last_frame: Optional[_Frame] = None   # inspection aid (tests / profiling); replaced every call
         self.last_forward_outputs = {}
         module = self
@@ -180,20 +184,23 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         ctx.frame, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
                         q_pointcloud_camera, t_pointcloud_camera, ctx.camera_info, acc_alpha, last,
                         grad_rasterized_image.contiguous(), ctx.color_max_sh_band)
-                    ctx.frame.release()
-                    ctx.frame = None
+                    # the frame is NOT released here: like the reference's saved tensors it lives as long as the graph
+                    # node does, so backward(retain_graph=True) followed by another backward works; it goes back to the
+                    # pool when autograd drops the node (_Frame.__del__)
                 return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
 
         self._module_function = _module_function
 
     # ------------------------------------------------------------------ helpers
-    def _ctx_for(self, device: torch.device):
+    def _context_for(self, device: torch.device) -> "_native.Context":
         idx = device.index if device.index is not None else torch.cuda.current_device()
         if idx not in self._ctxs:
-            h = C.c_void_p()
-            _native.check(_native.lib().gs_create(idx, C.byref(h)), "gs_create")
-            self._ctxs[idx] = h
+            self._ctxs[idx] = _native.Context(idx)
         return self._ctxs[idx]
+
+    def _ctx_for(self, device: torch.device):
+        """The raw gs_ctx* of this module on `device` (profiling / diagnostics)."""
+        return self._context_for(device).handle
 
     def _c_config(self):
         c = self.config
@@ -239,16 +246,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         last = torch.empty(H, W, dtype=torch.int32, device=dev)
         count = torch.empty(H, W, dtype=torch.int32, device=dev)
         out = _native.GsForwardOut(_ptr(image), _ptr(depth), _ptr(acc_alpha), _ptr(last), _ptr(count))
-        ctxh = self._ctx_for(dev)
+        context = self._context_for(dev)
+        ctxh = context.handle
         frame_h = C.c_void_p()
         scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _native.check(_native.lib().gs_forward(ctxh, C.byref(scene), C.byref(cam), C.byref(cfg), C.byref(out),
                                                    1 if keep else 0, C.byref(frame_h), C.c_void_p(stream)), "gs_forward")
-        frame = _Frame(ctxh, frame_h, dev)
-        if not keep:
-            frame.release = lambda: None     # transient frames belong to the ctx; nothing to release
+        frame = _Frame(context, frame_h, dev, owned=keep)
         self.last_frame = frame
         self.last_forward_outputs = {"pixel_accumulated_alpha": acc_alpha, "pixel_offset_of_last_effective_point": last}
         return (image, depth, acc_alpha, last, count), frame
@@ -318,10 +324,3 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
             input_data.point_cloud, input_data.point_cloud_features, input_data.point_invalid_mask,
             input_data.point_object_id, input_data.q_pointcloud_camera, input_data.t_pointcloud_camera,
             camera_info, input_data.color_max_sh_band)
-
-    def __del__(self):
-        try:
-            for h in self._ctxs.values():
-                _native.lib().gs_destroy(h)
-        except Exception:
-            pass

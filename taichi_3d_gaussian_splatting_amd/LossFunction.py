@@ -93,14 +93,23 @@ class LossFunction(nn.Module):
         self.config = config
 
     def forward(self, predicted_image, ground_truth_image, point_invalid_mask=None, pointcloud_features=None):
-        """predicted_image / ground_truth_image: (B=1, C, H, W) or (C, H, W).  Returns (L, L1, LD_SSIM)."""
-        if predicted_image.dim() == 4:
-            if predicted_image.shape[0] != 1:
-                raise ValueError("the fused loss handles one image per call (the reference trains with batch_size=None)")
-            predicted_image = predicted_image[0]
-        if ground_truth_image.dim() == 4:
-            ground_truth_image = ground_truth_image[0]
-        L, terms = _L1SSIM.apply(predicted_image, ground_truth_image, self.config.lambda_value)
+        """predicted_image / ground_truth_image: (B, C, H, W) or (C, H, W), C = 3.  Returns (L, L1, LD_SSIM).
+        With B > 1 (LossFunction.py:21-33 accepts it; the reference trainer uses batch_size=None) the images are
+        equally sized, so the batch means of L1 and of size_average=True SSIM are the means of the per-image values:
+        the fused kernel runs once per image."""
+        if predicted_image.dim() == 3:
+            predicted_image = predicted_image.unsqueeze(0)
+        if ground_truth_image.dim() == 3:
+            ground_truth_image = ground_truth_image.unsqueeze(0)
+        if predicted_image.shape != ground_truth_image.shape:
+            raise ValueError("predicted_image and ground_truth_image must have the same shape")
+        per_image = [_L1SSIM.apply(predicted_image[b], ground_truth_image[b], self.config.lambda_value)
+                     for b in range(predicted_image.shape[0])]
+        if len(per_image) == 1:
+            L, terms = per_image[0]
+        else:
+            L = torch.stack([p[0] for p in per_image]).mean()
+            terms = torch.stack([p[1] for p in per_image]).mean(dim=0)
         L1, LD_SSIM = terms[1], terms[2]
         if pointcloud_features is not None and self.config.enable_regularization:
             L = L + self.config.regularization_weight * self._regularization_loss(point_invalid_mask, pointcloud_features)

@@ -6,11 +6,12 @@ is missing or does not load, every entry point of this package raises -- loudly.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
 LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -40,7 +41,11 @@ class GsForwardOut(C.Structure):
 class GsFrameInfo(C.Structure):
     _fields_ = [("n_points", _I64), ("n_points_in_camera", _I64), ("n_keys", _I64), ("n_tiles", _I32),
                 ("camera_height", _I32), ("camera_width", _I32), ("sort_key_bits", _I32),
-                ("kept_for_backward", _I32)]
+                ("kept_for_backward", _I32), ("stages", _I32)]
+
+
+STAGE_PROJECT, STAGE_RASTER = 1, 2
+RECORD_FLOATS, SPLAT_SUM_FLOATS = 16, 12
 
 
 class GsControllerAccumulators(C.Structure):
@@ -83,7 +88,8 @@ EXPORTS = {
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
            "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
-           "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad"]
+           "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
+           "gs_project_shard", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
 
 _lib = None
 
@@ -122,10 +128,17 @@ def lib():
     L.gs_destroy.argtypes = [_VP]
     L.gs_forward.argtypes = [_VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig),
                              C.POINTER(GsForwardOut), _I32, C.POINTER(_VP), _VP]
-    L.gs_frame_get_info.argtypes = [_VP, C.POINTER(GsFrameInfo)]
-    L.gs_frame_export_count.argtypes = [_VP, C.c_int]
+    L.gs_frame_get_info.argtypes = [_VP, _VP, C.POINTER(GsFrameInfo)]
+    L.gs_frame_export_count.argtypes = [_VP, _VP, C.c_int]
     L.gs_frame_export_count.restype = _I64
-    L.gs_frame_export.argtypes = [_VP, C.c_int, _VP, _VP]
+    L.gs_frame_export.argtypes = [_VP, _VP, C.c_int, _VP, _VP]
+    L.gs_project_shard.argtypes = [_VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig), _VP, _VP, _I32,
+                                   C.POINTER(_VP), _VP]
+    L.gs_forward_projected.argtypes = [_VP, _VP, _I64, C.POINTER(GsCamera), C.POINTER(GsConfig), C.POINTER(GsForwardOut), _I32,
+                                       C.POINTER(_VP), _VP]
+    L.gs_backward_projected.argtypes = [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]
+    L.gs_backward_shard.argtypes = [_VP, _VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig), _VP, _I32,
+                                    C.POINTER(GsBackwardOut), _VP]
     L.gs_backward.argtypes = [_VP, _VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig),
                               _VP, _VP, _VP, _I32, C.POINTER(GsBackwardOut), _VP]
     L.gs_frame_release.argtypes = [_VP, _VP]
@@ -149,13 +162,30 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
 
 
+class Context:
+    """Owner of one gs_ctx.  Everything that can outlive the operator module -- above all the frame handles autograd keeps
+    between forward and backward -- holds a strong reference to this object, and gs_destroy runs only from its finaliser,
+    i.e. after the last frame is gone; never while the interpreter is shutting down (the HIP runtime may already be)."""
+
+    def __init__(self, device_index: int):
+        self.handle = C.c_void_p()
+        self.device_index = device_index
+        check(lib().gs_create(device_index, C.byref(self.handle)), "gs_create")
+
+    def __del__(self):
+        try:
+            if self.handle and sys is not None and not sys.is_finalizing():
+                lib().gs_destroy(self.handle)
+            self.handle = None
+        except Exception:
+            pass
+
+
 _shared_ctx = {}
 
 
 def shared_ctx(device_index: int):
     """A process-wide gs_ctx per device for the stateless helpers (loss, Adam)."""
     if device_index not in _shared_ctx:
-        h = C.c_void_p()
-        check(lib().gs_create(device_index, C.byref(h)), "gs_create")
-        _shared_ctx[device_index] = h
-    return _shared_ctx[device_index]
+        _shared_ctx[device_index] = Context(device_index)
+    return _shared_ctx[device_index].handle

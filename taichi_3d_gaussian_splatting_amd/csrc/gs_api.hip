@@ -60,8 +60,10 @@ struct FrameBufs {
     }
 };
 
-struct gs_frame {
-    gs_ctx* ctx = nullptr;
+// A frame as the library sees it.  Callers hold an opaque ticket (index + generation, encoded in the gs_frame* value)
+// that is resolved under the ctx mutex on every use, so a released, recycled or foreign handle is an error, never a
+// dereference of freed memory.
+struct Frame {
     FrameBufs* bufs = nullptr;
     gs_frame_info info{};
     int depth_bits = 0;
@@ -69,6 +71,7 @@ struct gs_frame {
     int key64 = 0;
     int32_t* vals_sorted = nullptr;
     bool live = false;
+    uint32_t generation = 0;
 };
 
 struct GsProf {
@@ -106,13 +109,18 @@ struct gs_ctx {
     std::mutex mu;
     int64_t device_bytes = 0;
     std::vector<FrameBufs*> pool;
-    std::vector<gs_frame*> frames;      // every handle ever issued (recycled)
-    gs_frame* transient = nullptr;      // frame of the last keep_for_backward == 0 call
+    std::vector<Frame*> frames;         // slot i of the ticket space (recycled, generation-tagged)
+    int transient = -1;                 // slot of the frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
     DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums, loss_ws;
     GsCounters* host_counters = nullptr;   // pinned, device-visible; written by k_scan_tiles_publish
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
     int32_t ticket = 0;                    // sequence number of the last forward
+    // stream hand-over: the scratch above is recycled in stream order, so work arriving on another stream waits for
+    // everything issued on the previous one
+    bool has_stream = false;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t switch_event = nullptr;
 };
 
 extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -120,7 +128,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" const char* gs_kernel_names(void)
 {
-    return "k_pose_prepare,k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,k_sort_row_totals,"
+    return "k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,k_sort_row_totals,"
            "k_sort_rowscan,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
 }
 
@@ -139,7 +147,9 @@ extern "C" int gs_create(int32_t device, gs_ctx** out)
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_counters_dev), c->host_counters, 0);
     if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
     e = c->counters.ensure(sizeof(GsCounters), &c->device_bytes);
-    if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: counters"); }
+    if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(GsCounters));      // every later frame leaves them reset (k_scan_tiles_publish)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->switch_event, hipEventDisableTiming);
+    if (e != hipSuccess) { c->counters.release(&c->device_bytes); (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: counters"); }
     *out = c;
     return GS_OK;
 }
@@ -150,12 +160,13 @@ extern "C" int gs_destroy(gs_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
-    for (gs_frame* f : c->frames) delete f;
+    for (Frame* f : c->frames) delete f;
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
                       &c->counters, &c->partial, &c->visited, &c->sums, &c->loss_ws };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
+    if (c->switch_event) (void)hipEventDestroy(c->switch_event);
     if (c->host_counters) (void)hipHostFree(c->host_counters);
     delete c;
     return GS_OK;
@@ -190,6 +201,24 @@ extern "C" int gs_profile_read(gs_ctx* c, double* total_ms, int64_t* launches, i
 
 extern "C" int64_t gs_ctx_device_bytes(const gs_ctx* c) { return c ? c->device_bytes : 0; }
 
+// ---- frame tickets ------------------------------------------------------------------------------------------------
+static gs_frame* ticket_of(int slot, uint32_t generation)
+{
+    return reinterpret_cast<gs_frame*>((uintptr_t)(((uint64_t)generation << 32) | (uint64_t)(uint32_t)(slot + 1)));
+}
+
+// resolves a ticket (mutex held); nullptr for anything that is not a live frame of THIS ctx
+static Frame* resolve(gs_ctx* c, const gs_frame* h, int* slot_out = nullptr)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)h;
+    const uint32_t lo = (uint32_t)v, gen = (uint32_t)(v >> 32);
+    if (lo == 0 || lo > c->frames.size()) return nullptr;
+    Frame* f = c->frames[lo - 1];
+    if (!f->live || f->generation != gen) return nullptr;
+    if (slot_out) *slot_out = (int)lo - 1;
+    return f;
+}
+
 static FrameBufs* acquire_bufs(gs_ctx* c)
 {
     for (FrameBufs* b : c->pool) if (!b->in_use) { b->in_use = true; return b; }
@@ -199,21 +228,36 @@ static FrameBufs* acquire_bufs(gs_ctx* c)
     return b;
 }
 
-static gs_frame* acquire_frame(gs_ctx* c)
+static Frame* acquire_frame(gs_ctx* c, int* slot)
 {
-    for (gs_frame* f : c->frames) if (!f->live) { f->live = true; return f; }
-    gs_frame* f = new gs_frame();
-    f->ctx = c; f->live = true;
+    for (size_t i = 0; i < c->frames.size(); ++i)
+        if (!c->frames[i]->live) { Frame* f = c->frames[i]; f->live = true; f->generation += 1; if (f->generation == 0) f->generation = 1; *slot = (int)i; return f; }
+    Frame* f = new Frame();
+    f->live = true; f->generation = 1;
     c->frames.push_back(f);
+    *slot = (int)c->frames.size() - 1;
     return f;
 }
 
-static void drop_frame(gs_ctx* c, gs_frame* f)
+static void drop_frame(gs_ctx* c, Frame* f)
 {
     if (!f || !f->live) return;
     if (f->bufs) f->bufs->in_use = false;
     f->bufs = nullptr; f->live = false;
-    if (c->transient == f) c->transient = nullptr;
+    for (size_t i = 0; i < c->frames.size(); ++i) if (c->frames[i] == f && c->transient == (int)i) c->transient = -1;
+}
+
+// Entering a call that launches on stream s (mutex held).
+static hipError_t enter_stream(gs_ctx* c, hipStream_t s)
+{
+    if (c->has_stream && c->last_stream != s) {
+        hipError_t e = hipEventRecord(c->switch_event, c->last_stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(s, c->switch_event, 0);
+        if (e != hipSuccess) return e;
+    }
+    c->has_stream = true; c->last_stream = s;
+    return hipSuccess;
 }
 
 static int bits_for(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b < 1 ? 1 : b; }
@@ -233,46 +277,90 @@ static int bits_for(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return 
         }                                                                                          \
     } while (0)
 
-extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
-                          const gs_forward_out* out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
+static void set_records(GsProjectArgs& pa, const FrameBufs& B, size_t rows)
+{   // GS_RS == 4: one 64-byte row per point; GS_RS == 1: four planes of `rows` records
+    float4* rec = B.rec.as<float4>();
+    const size_t plane = GS_RS == 4 ? 1 : rows;
+    pa.PA = rec; pa.PB = rec + plane; pa.PC = rec + 2 * plane; pa.PD = rec + 3 * plane;
+}
+
+// The one device->host hand-over of a frame: M, K, the depth-code range (and the bad-object-id count).  The last
+// prologue kernel writes them into pinned host memory and then the ticket; spinning on it costs a few microseconds
+// where a copy + stream synchronisation left the GPU idle for ~30.
+static int wait_counters(gs_ctx* c, hipStream_t s, int32_t ticket)
 {
-    if (!c || !sc || !cam || !cfg || !out || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL argument");
+    static const bool wait_on_stream = []{ const char* e = getenv("GS_COUNTERS_WAIT"); return e && std::strcmp(e, "stream") == 0; }();
+    if (wait_on_stream) {                   // diagnostic alternative: block in the runtime instead of spinning
+        HIP_TRY(hipStreamSynchronize(s));
+        return GS_OK;
+    }
+    volatile GsCounters* hc = c->host_counters;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0; hc->reserved != ticket; ++spin) {
+        if ((spin & 0xfffu) == 0xfffu) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {                         // stream drained: the ticket must be there now
+                if (hc->reserved != ticket) return fail(GS_ERR_HIP, "frame counters were not published");
+                break;
+            }
+            if (q != hipErrorNotReady) return fail(GS_ERR_HIP, std::string("waiting for the frame counters: ") + hipGetErrorString(q));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                return fail(GS_ERR_HIP, "timed out waiting for the frame counters");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GS_OK;
+}
+
+static int check_geometry(const gs_camera* cam, const gs_config* cfg, const char* who, int* tiles_x, int* tiles_y)
+{
     const int H = cam->camera_height, W = cam->camera_width;
     if (W <= 0 || H <= 0 || (!cfg->allow_partial_tiles && (W % GS_TILE != 0 || H % GS_TILE != 0)))        // RAST:1193-1194
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: camera_width and camera_height must be positive multiples of 16 "
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": camera_width and camera_height must be positive multiples of 16 "
                                              "(or set gs_config.allow_partial_tiles)");
-    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
-    if (tiles_x > 65535 || tiles_y > 65535) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: image too large");
+    *tiles_x = (W + GS_TILE - 1) / GS_TILE; *tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    if (*tiles_x > 65535 || *tiles_y > 65535) return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": image too large");
+    return GS_OK;
+}
+
+static int check_scene(const gs_scene* sc, const gs_camera* cam, const char* who)
+{
     const int64_t N = sc->n_points;
-    if (N < 0 || N >= (int64_t)1 << 31) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_points out of range");
-    if (cam->n_objects <= 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: n_objects must be >= 1");
+    if (N < 0 || N >= (int64_t)1 << 31) return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": n_points out of range");
+    if (cam->n_objects <= 0) return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": n_objects must be >= 1");
     if (N > 0 && (!sc->point_cloud || !sc->point_cloud_features || !sc->point_invalid_mask || !sc->point_object_id))
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL scene array");
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL scene array");
     if (!cam->q_pointcloud_camera || !cam->t_pointcloud_camera || !cam->camera_intrinsics)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL camera array");
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL camera array");
     if (((uintptr_t)sc->point_cloud_features & 15u) != 0)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: point_cloud_features must be 16-byte aligned");
-    if (!out->rasterized_image) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: rasterized_image is NULL");
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": point_cloud_features must be 16-byte aligned");
+    return GS_OK;
+}
+
+static int check_forward_out(const gs_forward_out* out, const gs_config* cfg, int keep, const char* who)
+{
+    if (!out->rasterized_image) return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": rasterized_image is NULL");
     if (!cfg->rgb_only && (!out->rasterized_depth || !out->pixel_accumulated_alpha ||
                            !out->pixel_offset_of_last_effective_point || !out->pixel_valid_point_count))
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: an output is NULL although rgb_only is false");
-    if (keep && cfg->rgb_only) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: rgb_only frames cannot be kept for backward (RAST:478-484)");
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": an output is NULL although rgb_only is false");
+    if (keep && cfg->rgb_only) return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": rgb_only frames cannot be kept for backward (RAST:478-484)");
+    return GS_OK;
+}
 
-    std::lock_guard<std::mutex> lock(c->mu);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    HIP_TRY(hipSetDevice(c->device));
-    if (c->transient) drop_frame(c, c->transient);
-    gs_frame* f = acquire_frame(c);
-    f->bufs = acquire_bufs(c);
+// ---- per-point half: filter, compaction, projection (+ tile counts, scan, publication) ----------------------------
+// On success the frame's buffers hold mask / ids / cam_index / records / box / ntiles and M, K, max_code are known.
+static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg, int T,
+                             hipStream_t s, GsProjectArgs* pa_out, int* M_out, uint32_t* K_out, int* max_code_out)
+{
     FrameBufs& B = *f->bufs;
-    const int T = tiles_x * tiles_y;
+    const int64_t N = sc->n_points;
+    const int H = cam->camera_height, W = cam->camera_width;
     const size_t nb = (size_t)((N + 255) / 256);
     const size_t Np = (size_t)(N > 0 ? N : 1);
-
     ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
     ENSURE(B.rec, 64 * Np);
     ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.offsets, 4 * Np);
-    ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared by ONE memset
+    ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared together
     ENSURE(B.tile_order, 4 * (size_t)T);
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
     ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
@@ -287,11 +375,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     pa.pose = B.pose.as<GsPose>(); pa.mask = B.mask.as<int8_t>();
     pa.block_counts = c->block_counts.as<int32_t>(); pa.block_offsets = c->block_offsets.as<int32_t>();
     pa.ids = B.ids.as<int32_t>(); pa.cam_index = B.cam_index.as<int32_t>();
-    {   // GS_RS == 4: one 64-byte row per point; GS_RS == 1: four planes of Np records
-        float4* rec = B.rec.as<float4>();
-        const size_t plane = GS_RS == 4 ? 1 : Np;
-        pa.PA = rec; pa.PB = rec + plane; pa.PC = rec + 2 * plane; pa.PD = rec + 3 * plane;
-    }
+    set_records(pa, B, Np);
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
@@ -300,38 +384,32 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_project(pa, s);
     HIP_TRY_F(hipGetLastError());
-    // the one device->host hand-over of the frame: M, K and the depth-code range.  The last kernel writes them into
-    // pinned host memory and then the ticket; spinning on it costs a few microseconds where a copy + stream
-    // synchronisation left the GPU idle for ~30.
-    static const bool wait_on_stream = []{ const char* e = getenv("GS_COUNTERS_WAIT"); return e && std::strcmp(e, "stream") == 0; }();
-    if (N > 0 && wait_on_stream) {                   // diagnostic alternative: block in the runtime instead of spinning
-        HIP_TRY_F(hipStreamSynchronize(s));
-    } else if (N > 0) {
-        volatile GsCounters* hc = c->host_counters;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spin = 0; hc->reserved != pa.ticket; ++spin) {
-            if ((spin & 0xfffu) == 0xfffu) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q == hipSuccess) {                         // stream drained: the ticket must be there now
-                    if (hc->reserved != pa.ticket) { drop_frame(c, f); return fail(GS_ERR_HIP, "gs_forward: frame counters were not published"); }
-                    break;
-                }
-                if (q != hipErrorNotReady) { drop_frame(c, f); return fail(GS_ERR_HIP, std::string("gs_forward: ") + hipGetErrorString(q)); }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-                    drop_frame(c, f); return fail(GS_ERR_HIP, "gs_forward: timed out waiting for the frame counters");
-                }
-            }
+    if (N > 0) {
+        const int rc = wait_counters(c, s, pa.ticket);
+        if (rc != GS_OK) { drop_frame(c, f); return rc; }
+        if (c->host_counters->bad_object_ids != 0) {
+            drop_frame(c, f);
+            return fail(GS_ERR_INVALID_ARGUMENT, "point_object_id holds " + std::to_string(c->host_counters->bad_object_ids) +
+                                                 " value(s) outside [0, n_objects) on valid rows");
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
     }
-    const int M = N > 0 ? c->host_counters->M : 0;
-    const uint32_t K = N > 0 ? c->host_counters->K : 0u;
-    const int max_code = N > 0 ? c->host_counters->max_depth_code : 0;
-    if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
+    *M_out = N > 0 ? c->host_counters->M : 0;
+    *K_out = N > 0 ? c->host_counters->K : 0u;
+    *max_code_out = N > 0 ? c->host_counters->max_depth_code : 0;
+    *pa_out = pa;
+    return GS_OK;
+}
+
+// ---- per-pixel half: key build, sort, tile ranges, blend ----------------------------------------------------------
+static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_t n_rows, int M, uint32_t K, int max_code,
+                            int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s)
+{
+    FrameBufs& B = *f->bufs;
+    if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
     const int depth_bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
     const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
     const int key64 = depth_bits + tile_bits > 32 ? 1 : 0;      // compact 32-bit keys whenever they fit
-    if (depth_bits + tile_bits > 63) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: sort key needs more than 63 bits"); }
+    if (depth_bits + tile_bits > 63) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "sort key needs more than 63 bits"); }
     const size_t Kp = K > 0 ? K : 1;
     const size_t key_bytes = key64 ? 8 : 4;
     ENSURE(B.keys_a, key_bytes * Kp); ENSURE(B.keys_b, key_bytes * Kp); ENSURE(B.vals_a, 4 * Kp); ENSURE(B.vals_b, 4 * Kp);
@@ -340,7 +418,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
 
     GsBinArgs ba{};
     ba.prof = &c->prof;
-    ba.N = N; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
+    ba.N = n_rows; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
     ba.offsets = B.offsets.as<uint32_t>();
@@ -363,49 +441,182 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     // tile ranges are all zero when K == 0, so the kernel writes the "no contributor" values itself
     gs_launch_blend_fwd(fa, s);
     HIP_TRY_F(hipGetLastError());
-
     f->depth_bits = depth_bits;
     f->key64 = key64;
-    f->info.n_points = N; f->info.n_points_in_camera = M; f->info.n_keys = K; f->info.n_tiles = T;
-    f->info.camera_height = H; f->info.camera_width = W; f->info.sort_key_bits = depth_bits + tile_bits;
-    f->info.kept_for_backward = keep ? 1 : 0;
-    if (!keep) c->transient = f;
-    *frame_out = f;
+    f->info.sort_key_bits = depth_bits + tile_bits;
     return GS_OK;
 }
 
-extern "C" int gs_frame_get_info(const gs_frame* f, gs_frame_info* info)
+static void finish_frame(gs_ctx* c, Frame* f, int slot, int64_t N, int M, uint32_t K, int T, int H, int W, int keep, int stages,
+                         gs_frame** frame_out)
 {
-    if (!f || !info || !f->live) return fail(GS_ERR_STATE, "gs_frame_get_info: frame is not live");
+    f->info.n_points = N; f->info.n_points_in_camera = M; f->info.n_keys = K; f->info.n_tiles = T;
+    f->info.camera_height = H; f->info.camera_width = W;
+    f->info.kept_for_backward = keep ? 1 : 0;
+    f->info.stages = stages;
+    if (!keep) c->transient = slot;
+    *frame_out = ticket_of(slot, f->generation);
+}
+
+extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                          const gs_forward_out* out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !out || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward: NULL argument");
+    int tiles_x = 0, tiles_y = 0, rc;
+    if ((rc = check_geometry(cam, cfg, "gs_forward", &tiles_x, &tiles_y)) != GS_OK) return rc;
+    if ((rc = check_scene(sc, cam, "gs_forward")) != GS_OK) return rc;
+    if ((rc = check_forward_out(out, cfg, keep, "gs_forward")) != GS_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    if (c->transient >= 0) drop_frame(c, c->frames[c->transient]);
+    int slot = -1;
+    Frame* f = acquire_frame(c, &slot);
+    f->bufs = acquire_bufs(c);
+    f->info = gs_frame_info{};
+    const int T = tiles_x * tiles_y;
+    GsProjectArgs pa{};
+    int M = 0, max_code = 0; uint32_t K = 0;
+    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code)) != GS_OK) return rc;
+    if ((rc = run_raster_stage(c, f, pa, sc->n_points, M, K, max_code, cam->camera_height, cam->camera_width, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    finish_frame(c, f, slot, sc->n_points, M, K, T, cam->camera_height, cam->camera_width, keep, GS_STAGE_PROJECT | GS_STAGE_RASTER, frame_out);
+    return GS_OK;
+}
+
+extern "C" int gs_project_shard(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                                float* records_out, int32_t* ids_out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_project_shard: NULL argument");
+    if (sc->n_points > 0 && !records_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_project_shard: records_out is NULL");
+    if (((uintptr_t)records_out & 15u) != 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_project_shard: records_out must be 16-byte aligned");
+    int tiles_x = 0, tiles_y = 0, rc;
+    if ((rc = check_geometry(cam, cfg, "gs_project_shard", &tiles_x, &tiles_y)) != GS_OK) return rc;
+    if ((rc = check_scene(sc, cam, "gs_project_shard")) != GS_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    if (c->transient >= 0) drop_frame(c, c->frames[c->transient]);
+    int slot = -1;
+    Frame* f = acquire_frame(c, &slot);
+    f->bufs = acquire_bufs(c);
+    f->info = gs_frame_info{};
+    const int T = tiles_x * tiles_y;
+    GsProjectArgs pa{};
+    int M = 0, max_code = 0; uint32_t K = 0;
+    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code)) != GS_OK) return rc;
+    static_assert(GS_RS == 4, "the staged entry points hand records over as (M,16) rows");
+    if (M > 0) {
+        HIP_TRY_F(hipMemcpyAsync(records_out, f->bufs->rec.p, (size_t)M * 64, hipMemcpyDeviceToDevice, s));
+        if (ids_out) HIP_TRY_F(hipMemcpyAsync(ids_out, f->bufs->ids.p, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+    }
+    finish_frame(c, f, slot, sc->n_points, M, K, T, cam->camera_height, cam->camera_width, keep, GS_STAGE_PROJECT, frame_out);
+    return GS_OK;
+}
+
+extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, const gs_camera* cam, const gs_config* cfg,
+                                    const gs_forward_out* out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
+{
+    if (!c || !cam || !cfg || !out || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward_projected: NULL argument");
+    if (m < 0 || m >= (int64_t)1 << 31) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward_projected: m out of range");
+    if (m > 0 && !records) return fail(GS_ERR_INVALID_ARGUMENT, "gs_forward_projected: records is NULL");
+    int tiles_x = 0, tiles_y = 0, rc;
+    if ((rc = check_geometry(cam, cfg, "gs_forward_projected", &tiles_x, &tiles_y)) != GS_OK) return rc;
+    if ((rc = check_forward_out(out, cfg, keep, "gs_forward_projected")) != GS_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    if (c->transient >= 0) drop_frame(c, c->frames[c->transient]);
+    int slot = -1;
+    Frame* f = acquire_frame(c, &slot);
+    f->bufs = acquire_bufs(c);
+    f->info = gs_frame_info{};
+    FrameBufs& B = *f->bufs;
+    const int T = tiles_x * tiles_y, H = cam->camera_height, W = cam->camera_width;
+    const size_t Mp = (size_t)(m > 0 ? m : 1);
+    const size_t nb = (size_t)((m + 255) / 256);
+    ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
+    ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * (size_t)T);
+    ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
+    if (m > 0) HIP_TRY_F(hipMemcpyAsync(B.rec.p, records, (size_t)m * 64, hipMemcpyDeviceToDevice, s));   // the frame keeps its own copy for backward
+    GsProjectArgs pa{};
+    pa.prof = &c->prof; pa.N = m; pa.H = H; pa.W = W; pa.depth_scale = cfg->depth_to_sort_key_scale;
+    set_records(pa, B, Mp);
+    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
+    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
+    pa.counters = c->counters.as<GsCounters>();
+    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
+    pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
+    if (c->ticket == 0x7fffffff) c->ticket = 0;
+    gs_launch_boxes_from_records(pa, (int)m, s);
+    HIP_TRY_F(hipGetLastError());
+    uint32_t K = 0; int max_code = 0;
+    if (m > 0) {
+        if ((rc = wait_counters(c, s, pa.ticket)) != GS_OK) { drop_frame(c, f); return rc; }
+        K = c->host_counters->K; max_code = c->host_counters->max_depth_code;
+    }
+    if ((rc = run_raster_stage(c, f, pa, m, (int)m, K, max_code, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    finish_frame(c, f, slot, m, (int)m, K, T, H, W, keep, GS_STAGE_RASTER, frame_out);
+    return GS_OK;
+}
+
+extern "C" int gs_frame_get_info(gs_ctx* c, const gs_frame* h, gs_frame_info* info)
+{
+    if (!c || !info) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_get_info: NULL argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    const Frame* f = resolve(c, h);
+    if (!f) return fail(GS_ERR_STATE, "gs_frame_get_info: not a live frame of this context");
     *info = f->info;
     return GS_OK;
 }
 
-extern "C" int64_t gs_frame_export_count(const gs_frame* f, gs_export what)
+static int64_t export_count(const Frame* f, gs_export what)
 {
-    if (!f || !f->live) return -1;
     const int64_t M = f->info.n_points_in_camera, K = f->info.n_keys, T = f->info.n_tiles, N = f->info.n_points;
+    const bool proj = (f->info.stages & GS_STAGE_PROJECT) != 0, rast = (f->info.stages & GS_STAGE_RASTER) != 0;
     switch (what) {
-    case GS_X_POINT_ID_IN_CAMERA_LIST: case GS_X_POINT_ALPHA_AFTER_ACTIVATION: case GS_X_POINT_RADII:
-    case GS_X_NUM_OVERLAP_TILES: case GS_X_ACCUMULATED_NUM_OVERLAP_TILES: case GS_X_POINT_DEPTH: return M;
+    case GS_X_POINT_ID_IN_CAMERA_LIST: return proj ? M : -1;
+    case GS_X_POINT_IN_CAMERA_MASK: return proj ? N : -1;
+    case GS_X_POINT_ALPHA_AFTER_ACTIVATION: case GS_X_POINT_RADII: case GS_X_NUM_OVERLAP_TILES: case GS_X_POINT_DEPTH: return M;
+    case GS_X_ACCUMULATED_NUM_OVERLAP_TILES: return rast ? M : -1;
     case GS_X_POINT_UV: return 2 * M;
     case GS_X_POINT_IN_CAMERA: case GS_X_POINT_COLOR: return 3 * M;
     case GS_X_POINT_UV_CONIC_AND_RESCALE: return 4 * M;
-    case GS_X_SORT_KEY: case GS_X_POINT_OFFSET_WITH_SORT_KEY: return K;
-    case GS_X_TILE_POINTS_START: case GS_X_TILE_POINTS_END: return T;
-    case GS_X_POINT_IN_CAMERA_MASK: return N;
+    case GS_X_SORT_KEY: case GS_X_POINT_OFFSET_WITH_SORT_KEY: return rast ? K : -1;
+    case GS_X_TILE_POINTS_START: case GS_X_TILE_POINTS_END: return rast ? T : -1;
     default: return -1;
     }
 }
 
-extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_stream stream_)
+extern "C" int64_t gs_frame_export_count(gs_ctx* c, const gs_frame* h, gs_export what)
 {
-    if (!f || !f->live || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_export: frame is not live");
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const Frame* f = resolve(c, h);
+    return f ? export_count(f, what) : -1;
+}
+
+static void set_records(GsBackwardArgs& a, const FrameBufs& B, size_t rows)
+{
+    const float4* rec = B.rec.as<float4>();
+    const size_t plane = GS_RS == 4 ? 1 : rows;
+    a.PA = rec; a.PB = rec + plane; a.PC = rec + 2 * plane; a.PD = rec + 3 * plane;
+}
+
+extern "C" int gs_frame_export(gs_ctx* c, const gs_frame* h, gs_export what, void* dst, gs_stream stream_)
+{
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: ctx is NULL");
     if (!dst) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: dst is NULL");
     if (what < 0 || what >= GS_X_COUNT_) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: unknown export id");
-    gs_ctx* c = f->ctx;
     std::lock_guard<std::mutex> lock(c->mu);
+    const Frame* f = resolve(c, h);
+    if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_export: not a live frame of this context");
+    if (export_count(f, what) < 0) return fail(GS_ERR_STATE, "gs_frame_export: this frame does not hold that stage");
     HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(enter_stream(c, s));
     const FrameBufs& B = *f->bufs;
     GsExportArgs a{};
     a.what = (int)what; a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = (uint32_t)f->info.n_keys;
@@ -420,48 +631,36 @@ extern "C" int gs_frame_export(const gs_frame* f, gs_export what, void* dst, gs_
     a.keys_sorted = f->keys_sorted; a.vals_sorted = f->vals_sorted;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.mask = B.mask.as<int8_t>();
     a.dst = dst;
-    gs_launch_export(a, reinterpret_cast<hipStream_t>(stream_));
+    gs_launch_export(a, s);
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }
 
-extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
-                           const float* grad_image, const float* acc_alpha, const int32_t* last,
-                           int32_t sh_band, const gs_backward_out* out, gs_stream stream_)
+// ---- backward -----------------------------------------------------------------------------------------------------
+// waves per tile of the backward blend: one wave per tile is the cheapest in instructions, but a small image
+// has too few tiles to fill 1024 SIMDs, so tiles are split into 2 or 4 quadrant groups (more rows of `partial`)
+static int waves_per_tile(int n_tiles)
 {
-    if (!c || !f || !sc || !cam || !cfg || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL argument");
-    if (!f->live || !f->bufs || f->ctx != c) return fail(GS_ERR_STATE, "gs_backward: frame is not live on this context");
-    if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward: frame was not kept for backward");
-    if (!grad_image || !acc_alpha || !last) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL image-sized input");
-    if (sc->n_points > 0 && (!out->grad_pointcloud || !out->grad_pointcloud_features))
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: grad_pointcloud / grad_pointcloud_features are mandatory");
-    if (sc->n_points != f->info.n_points || cam->camera_height != f->info.camera_height || cam->camera_width != f->info.camera_width)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: scene/camera do not match the frame");
-    if (((uintptr_t)out->grad_pointcloud_features & 15u) != 0 || ((uintptr_t)sc->point_cloud_features & 15u) != 0)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: feature arrays must be 16-byte aligned");
-    if (out->hook_grad_pointfeatures_in_camera && ((uintptr_t)out->hook_grad_pointfeatures_in_camera & 15u) != 0)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: hook feature array must be 16-byte aligned");
-    std::lock_guard<std::mutex> lock(c->mu);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    HIP_TRY(hipSetDevice(c->device));
-    const uint32_t K = (uint32_t)f->info.n_keys;
-    // waves per tile of the backward blend: one wave per tile is the cheapest in instructions, but a small image
-    // has too few tiles to fill 1024 SIMDs, so tiles are split into 2 or 4 quadrant groups (more rows of `partial`)
     int G = 1;
     if (const char* e = getenv("GS_BWD_WAVES_PER_TILE")) G = atoi(e);
-    else if (f->info.n_tiles < 3072) G = 4;
-    else if (f->info.n_tiles < 6144) G = 2;
+    else if (n_tiles < 3072) G = 4;
+    else if (n_tiles < 6144) G = 2;
     if (G != 1 && G != 2 && G != 4) G = 1;
+    return G;
+}
+
+// fills the blend half of the arguments; sums_out = where the per-splat sums go
+static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_image, const float* acc_alpha, const int32_t* last,
+                                  float* mag_image, float4* sums_out, GsBackwardArgs* a_out)
+{
+    const uint32_t K = (uint32_t)f->info.n_keys;
+    const int G = waves_per_tile(f->info.n_tiles);
     const size_t rows = (size_t)(K > 0 ? K : 1) * (size_t)G;
     const size_t flag_bytes = (rows + 15) / 16 * 16;
-    {
-        hipError_t e = c->partial.ensure(rows * 12 * sizeof(float), &c->device_bytes);
-        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: partial-sum buffer");
-        e = c->visited.ensure(flag_bytes + 64, &c->device_bytes);
-        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: visited buffer");
-        e = c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes);
-        if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
-    }
+    hipError_t e = c->partial.ensure(rows * 12 * sizeof(float), &c->device_bytes);
+    if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: partial-sum buffer");
+    e = c->visited.ensure(flag_bytes + 64, &c->device_bytes);
+    if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: visited buffer");
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
     a.prof = &c->prof;
@@ -470,40 +669,134 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* f, const gs_scene* sc, const gs_
     a.tiles_x = (a.W + GS_TILE - 1) / GS_TILE;
     a.tile_start = B.tile_start.as<int32_t>(); a.tile_end = B.tile_start.as<int32_t>() + f->info.n_tiles; a.vals_sorted = f->vals_sorted;
     a.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)f->info.n_tiles; a.tile_order = B.tile_order.as<int32_t>();
-    {
-        const float4* rec = B.rec.as<float4>();
-        const size_t plane = GS_RS == 4 ? 1 : (size_t)(f->info.n_points > 0 ? f->info.n_points : 1);
-        a.PA = rec; a.PB = rec + plane; a.PC = rec + 2 * plane; a.PD = rec + 3 * plane;
-    }
+    set_records(a, B, (size_t)(f->info.n_points > 0 ? f->info.n_points : 1));
     a.box = B.box.as<ushort4>(); a.offsets = B.offsets.as<uint32_t>(); a.ntiles = B.ntiles.as<int32_t>();
-    a.ids = B.ids.as<int32_t>(); a.cam_index = B.cam_index.as<int32_t>();
     a.grad_image = grad_image; a.acc_alpha = acc_alpha; a.last = last;
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
     a.G = G;
     a.visited_bytes = flag_bytes + 48;
     a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + flag_bytes);
-    a.sums = c->sums.as<float4>();
-    a.point_cloud = sc->point_cloud; a.features = sc->point_cloud_features; a.object_id = sc->point_object_id;
-    a.Kmat = cam->camera_intrinsics; a.pose = B.pose.as<GsPose>();
-    a.sh_band = sh_band; a.f_color = cfg->grad_color_factor; a.f_high = cfg->grad_high_order_color_factor;
-    a.f_s = cfg->grad_s_factor; a.f_q = cfg->grad_q_factor; a.f_alpha = cfg->grad_alpha_factor;
-    a.grad_pc = out->grad_pointcloud; a.grad_feat = out->grad_pointcloud_features; a.grad_uv = out->grad_viewspace;
-    a.mag = out->magnitude_grad_viewspace; a.mag_image = out->magnitude_grad_viewspace_on_image;
-    a.n_affected = out->num_affected_pixels;
-    a.hook_gpc = out->hook_grad_point_in_camera; a.hook_gfeat = out->hook_grad_pointfeatures_in_camera;
-    a.hook_guv = out->hook_grad_viewspace; a.hook_mag = out->hook_magnitude_grad_viewspace;
-    a.hook_ids = out->hook_point_id_in_camera_list; a.hook_ntiles = out->hook_num_overlap_tiles;
-    a.hook_depth = out->hook_point_depth; a.hook_uv = out->hook_point_uv_in_camera;
+    a.sums = sums_out;
+    a.mag_image = mag_image;
+    *a_out = a;
+    return GS_OK;
+}
+
+static int prepare_backward_points(const Frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                                   int32_t sh_band, const gs_backward_out* out, const float4* sums, GsBackwardArgs* a)
+{
+    const FrameBufs& B = *f->bufs;
+    a->N = f->info.n_points; a->M = (int)f->info.n_points_in_camera;
+    set_records(*a, B, (size_t)(f->info.n_points > 0 ? f->info.n_points : 1));
+    a->ntiles = B.ntiles.as<int32_t>();
+    a->ids = B.ids.as<int32_t>(); a->cam_index = B.cam_index.as<int32_t>();
+    a->sums = const_cast<float4*>(sums);
+    a->point_cloud = sc->point_cloud; a->features = sc->point_cloud_features; a->object_id = sc->point_object_id;
+    a->Kmat = cam->camera_intrinsics; a->pose = B.pose.as<GsPose>();
+    a->sh_band = sh_band; a->f_color = cfg->grad_color_factor; a->f_high = cfg->grad_high_order_color_factor;
+    a->f_s = cfg->grad_s_factor; a->f_q = cfg->grad_q_factor; a->f_alpha = cfg->grad_alpha_factor;
+    a->grad_pc = out->grad_pointcloud; a->grad_feat = out->grad_pointcloud_features; a->grad_uv = out->grad_viewspace;
+    a->mag = out->magnitude_grad_viewspace;
+    a->n_affected = out->num_affected_pixels;
+    a->hook_gpc = out->hook_grad_point_in_camera; a->hook_gfeat = out->hook_grad_pointfeatures_in_camera;
+    a->hook_guv = out->hook_grad_viewspace; a->hook_mag = out->hook_magnitude_grad_viewspace;
+    a->hook_ids = out->hook_point_id_in_camera_list; a->hook_ntiles = out->hook_num_overlap_tiles;
+    a->hook_depth = out->hook_point_depth; a->hook_uv = out->hook_point_uv_in_camera;
     if (const gs_controller_accumulators* ca = out->controller) {
         if (!ca->accumulated_num_in_camera || !ca->accumulated_num_pixels || !ca->accumulated_view_space_position_gradients ||
             !ca->accumulated_view_space_position_gradients_avg || !ca->accumulated_position_gradients || !ca->accumulated_position_gradients_norm)
-            return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: controller accumulators must all be given");
-        a.c_num_in_camera = ca->accumulated_num_in_camera; a.c_num_pixels = ca->accumulated_num_pixels;
-        a.c_vs_grad = ca->accumulated_view_space_position_gradients; a.c_vs_grad_avg = ca->accumulated_view_space_position_gradients_avg;
-        a.c_pos_grad = ca->accumulated_position_gradients; a.c_pos_grad_norm = ca->accumulated_position_gradients_norm;
+            return fail(GS_ERR_INVALID_ARGUMENT, "backward: controller accumulators must all be given");
+        a->c_num_in_camera = ca->accumulated_num_in_camera; a->c_num_pixels = ca->accumulated_num_pixels;
+        a->c_vs_grad = ca->accumulated_view_space_position_gradients; a->c_vs_grad_avg = ca->accumulated_view_space_position_gradients_avg;
+        a->c_pos_grad = ca->accumulated_position_gradients; a->c_pos_grad_norm = ca->accumulated_position_gradients_norm;
     }
-    gs_launch_backward(a, s);
+    return GS_OK;
+}
+
+static int check_backward_points_args(const Frame* f, const gs_scene* sc, const gs_camera* cam, const gs_backward_out* out, const char* who)
+{
+    if (sc->n_points > 0 && (!out->grad_pointcloud || !out->grad_pointcloud_features))
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": grad_pointcloud / grad_pointcloud_features are mandatory");
+    if (sc->n_points != f->info.n_points || cam->camera_height != f->info.camera_height || cam->camera_width != f->info.camera_width)
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": scene/camera do not match the frame");
+    if (((uintptr_t)out->grad_pointcloud_features & 15u) != 0 || ((uintptr_t)sc->point_cloud_features & 15u) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": feature arrays must be 16-byte aligned");
+    if (out->hook_grad_pointfeatures_in_camera && ((uintptr_t)out->hook_grad_pointfeatures_in_camera & 15u) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, std::string(who) + ": hook feature array must be 16-byte aligned");
+    return GS_OK;
+}
+
+extern "C" int gs_backward(gs_ctx* c, gs_frame* h, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                           const float* grad_image, const float* acc_alpha, const int32_t* last,
+                           int32_t sh_band, const gs_backward_out* out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL argument");
+    if (!grad_image || !acc_alpha || !last) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward: NULL image-sized input");
+    std::lock_guard<std::mutex> lock(c->mu);
+    Frame* f = resolve(c, h);
+    if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_backward: not a live frame of this context");
+    if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward: frame was not kept for backward");
+    if (f->info.stages != (GS_STAGE_PROJECT | GS_STAGE_RASTER)) return fail(GS_ERR_STATE, "gs_backward: frame does not come from gs_forward");
+    int rc;
+    if ((rc = check_backward_points_args(f, sc, cam, out, "gs_backward")) != GS_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    if (c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes) != hipSuccess)
+        return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
+    GsBackwardArgs a{};
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), &a)) != GS_OK) return rc;
+    if ((rc = prepare_backward_points(f, sc, cam, cfg, sh_band, out, c->sums.as<float4>(), &a)) != GS_OK) return rc;
+    gs_launch_backward_blend(a, s);
+    gs_launch_backward_points(a, s);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_backward_projected(gs_ctx* c, gs_frame* h, const float* grad_image, const float* acc_alpha, const int32_t* last,
+                                     float* splat_sums_out, float* mag_image, gs_stream stream_)
+{
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_projected: ctx is NULL");
+    if (!grad_image || !acc_alpha || !last) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_projected: NULL image-sized input");
+    if (((uintptr_t)splat_sums_out & 15u) != 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_projected: splat_sums_out must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(c->mu);
+    Frame* f = resolve(c, h);
+    if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_backward_projected: not a live frame of this context");
+    if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward_projected: frame was not kept for backward");
+    if (!(f->info.stages & GS_STAGE_RASTER)) return fail(GS_ERR_STATE, "gs_backward_projected: frame holds no raster stage");
+    if (f->info.n_points_in_camera > 0 && !splat_sums_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_projected: splat_sums_out is NULL");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    GsBackwardArgs a{};
+    int rc;
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), &a)) != GS_OK) return rc;
+    gs_launch_backward_blend(a, s);
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_backward_shard(gs_ctx* c, gs_frame* h, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                                 const float* splat_sums, int32_t sh_band, const gs_backward_out* out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_shard: NULL argument");
+    if (((uintptr_t)splat_sums & 15u) != 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_shard: splat_sums must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(c->mu);
+    Frame* f = resolve(c, h);
+    if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_backward_shard: not a live frame of this context");
+    if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward_shard: frame was not kept for backward");
+    if (!(f->info.stages & GS_STAGE_PROJECT)) return fail(GS_ERR_STATE, "gs_backward_shard: frame holds no projection stage");
+    if (f->info.n_points_in_camera > 0 && !splat_sums) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_shard: splat_sums is NULL");
+    int rc;
+    if ((rc = check_backward_points_args(f, sc, cam, out, "gs_backward_shard")) != GS_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    GsBackwardArgs a{};
+    a.prof = &c->prof;
+    if ((rc = prepare_backward_points(f, sc, cam, cfg, sh_band, out, reinterpret_cast<const float4*>(splat_sums), &a)) != GS_OK) return rc;
+    gs_launch_backward_points(a, s);
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }
@@ -517,6 +810,7 @@ extern "C" int gs_loss_l1_ssim(gs_ctx* c, const float* pred, const float* gt, in
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = c->loss_ws.ensure(gs_loss_workspace_floats(H, W) * sizeof(float), &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_loss_l1_ssim: workspace");
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
     gs_launch_loss(pred, gt, H, W, lambda_value, c->loss_ws.as<float>(), loss_terms, grad_pred, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
     return GS_OK;
@@ -530,6 +824,7 @@ extern "C" int gs_scale_regulariser(gs_ctx* c, const float* feat, const int8_t* 
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = c->loss_ws.ensure((size_t)(2 * ((n + 255) / 256) + 16) * sizeof(float), &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_scale_regulariser: workspace");
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
     gs_launch_reg_value(feat, mask, n, c->loss_ws.as<float>(), out, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
     return GS_OK;
@@ -543,6 +838,7 @@ extern "C" int gs_scale_regulariser_grad(gs_ctx* c, const float* feat, const int
     if (grad && ((uintptr_t)grad & 15u) != 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_scale_regulariser_grad: grad must be 16-byte aligned");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
     gs_launch_reg_grad(feat, mask, n, value_and_count, upstream, grad, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
     return GS_OK;
@@ -555,16 +851,18 @@ extern "C" int gs_adam_step(gs_ctx* c, float* param, const float* grad, float* e
     if (n < 0 || step < 1) return fail(GS_ERR_INVALID_ARGUMENT, "gs_adam_step: n must be >= 0 and step >= 1");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
     gs_launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }
 
-extern "C" int gs_frame_release(gs_ctx* c, gs_frame* f)
+extern "C" int gs_frame_release(gs_ctx* c, gs_frame* h)
 {
-    if (!c || !f) return GS_OK;
-    if (f->ctx != c) return fail(GS_ERR_STATE, "gs_frame_release: frame belongs to another context");
+    if (!c || !h) return GS_OK;
     std::lock_guard<std::mutex> lock(c->mu);
+    Frame* f = resolve(c, h);
+    if (!f) return fail(GS_ERR_STATE, "gs_frame_release: not a live frame of this context (already released?)");
     drop_frame(c, f);
     return GS_OK;
 }

@@ -38,7 +38,7 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #define GS_T_STOP 0.0001f            // RAST:458
 #define GS_NFEAT 56
 
-// Per-object pose record built once per frame by k_pose_prepare.
+// Per-object pose record built once per frame (every k_filter block derives it, block 0 stores it).
 struct GsPose {
     float R[9];          // rotation_matrix_from_quaternion(conj(q_pointcloud_camera)), GP3D:30-48
     float t[3];          // t_camera_pointcloud, UTIL:426-432
@@ -53,7 +53,9 @@ struct GsCounters {
     int32_t M;               // points in camera
     uint32_t K;              // sort pairs
     int32_t max_depth_code;  // max over visible points of i32(depth * scale)
-    int32_t reserved;
+    int32_t reserved;        // host mirror only: ticket of the forward that published these values
+    int32_t bad_object_ids;  // valid rows whose point_object_id is outside [0, n_objects): treated as not in camera, reported
+    int32_t pad[3];
 };
 
 // ---- device math -------------------------------------------------------------
@@ -165,7 +167,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 
 // ---- optional per-kernel timing with HIP events on the launch stream -------------
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
-enum GsKernelId { KID_POSE = 0, KID_FILTER, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
+enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
                   KID_SORT_HIST, KID_SORT_TOTALS, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
                   KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
@@ -191,6 +193,9 @@ struct GsProjectArgs {
     GsCounters* host_mirror; int32_t ticket;    // pinned host copy of the counters; .reserved = ticket once they are valid
 };
 void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
+// the per-pixel half started from records (gs_forward_projected): tile boxes, counts, block sums and the depth-code range
+// from the records, then the same scan + publication as gs_launch_project
+void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s);
 
 struct GsBinArgs {
     GsProf* prof;
@@ -231,7 +236,7 @@ struct GsBackwardArgs {
     uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward
     size_t visited_bytes;           // K rounded up to 16 + 48: flags, then one all-zero 48-byte row
     const float4* zero_row;         // that row
-    float4* sums;                   // (M,3) per-point sums of the visited rows
+    float4* sums;                   // (M,3) per-point sums of the visited rows (count as int32 bits in [10])
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;
     float* grad_pc; float* grad_feat; float* grad_uv; float* mag; float* mag_image; int32_t* n_affected;
@@ -240,7 +245,8 @@ struct GsBackwardArgs {
     // adaptive-controller accumulators (CTRL:114-141), all nullable together
     int32_t* c_num_in_camera; int32_t* c_num_pixels; float* c_vs_grad; float* c_vs_grad_avg; float* c_pos_grad; float* c_pos_grad_norm;
 };
-void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s);
+void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s);     // tile order, blend backward, per-splat sums -> a.sums
+void gs_launch_backward_points(const GsBackwardArgs& a, hipStream_t s);    // a.sums -> every gradient / hook array
 
 struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_bits; int key64;
     const int32_t* ids; const float4 *PA, *PB, *PC, *PD; const int32_t* ntiles; const uint32_t* offsets;

@@ -20,7 +20,7 @@
 #include <cstdlib>
 
 #define RED_STRIDE 68   // floats per value row of the LDS transpose (64 lanes + 4 pad: conflict-free b128 reads)
-#define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count | pad
+#define PW 12     // floats per partial row: vs0 vs1 | cov00 cov01 cov11 | col r g b | opacity | |vs| | count (int32 bits) | pad
 
 // ---------------------------------------------------------------------------------
 // Loop 1: ONE WAVE PER TILE, four pixels per lane (one per 8x8 quadrant).
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     }
                     t += gs_dpp<0xB1>(t);              // quad_perm [1,0,3,2]
                     t += gs_dpp<0x4E>(t);              // quad_perm [2,3,0,1]
-                    if (lane == 40) t = (float)n_use;
+                    if (lane == 40) t = __int_as_float(n_use);      // the count travels as an integer end to end (exact for any image size)
                     const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
                     float* row = partial + (size_t)sj * PW;
                     if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
     const uint32_t off = valid ? offsets[m] * (uint32_t)G : 0u;      // G rows per (point, tile) pair
     const int cnt = valid ? ntiles[m] * G : 0;
     float v[11];
+    int npix = 0;                                                     // column 10 is an integer count: summed as one
 #pragma unroll
     for (int k = 0; k < 11; ++k) v[k] = 0.0f;
     if (cnt <= SUM_ROWS_SMALL) {
@@ -310,17 +311,19 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
             for (int k = 0; k < 4; ++k) {
                 v[0] += a[k].x; v[1] += a[k].y; v[2] += a[k].z; v[3] += a[k].w;
                 v[4] += b[k].x; v[5] += b[k].y; v[6] += b[k].z; v[7] += b[k].w;
-                v[8] += c[k].x; v[9] += c[k].y; v[10] += c[k].z;
+                v[8] += c[k].x; v[9] += c[k].y; npix += __float_as_int(c[k].z);
             }
         }
     }
     GS_DPP11("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
     GS_DPP11("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
     asm volatile("s_nop 1");
+    npix += __builtin_amdgcn_update_dpp(0, npix, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    npix += __builtin_amdgcn_update_dpp(0, npix, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
     if (valid && q == 0 && cnt <= SUM_ROWS_SMALL) {
         sums[3 * (size_t)m] = make_float4(v[0], v[1], v[2], v[3]);
         sums[3 * (size_t)m + 1] = make_float4(v[4], v[5], v[6], v[7]);
-        sums[3 * (size_t)m + 2] = make_float4(v[8], v[9], v[10], 0.0f);
+        sums[3 * (size_t)m + 2] = make_float4(v[8], v[9], __int_as_float(npix), 0.0f);
     }
     // wave-cooperative pass over the large points of this wave (one vote per quad leader)
     unsigned long long big = gs_ballot(valid && q == 0 && cnt > SUM_ROWS_SMALL);
@@ -333,20 +336,22 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
         const float4* rows = reinterpret_cast<const float4*>(partial + (size_t)boff * PW);
         const uint8_t* vis = visited + boff;
         float w[11];
+        int wpix = 0;
 #pragma unroll
         for (int k = 0; k < 11; ++k) w[k] = 0.0f;
         for (int i = lane; i < bcnt; i += 64) {
             if (vis[i]) {
                 const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
                 w[0] += a.x; w[1] += a.y; w[2] += a.z; w[3] += a.w; w[4] += b.x; w[5] += b.y; w[6] += b.z; w[7] += b.w;
-                w[8] += c.x; w[9] += c.y; w[10] += c.z;
+                w[8] += c.x; w[9] += c.y; wpix += __float_as_int(c.z);
             }
         }
         gs_wave_sum11_row3(w);
+        wpix = gs_wave_sum_i(wpix);
         if (lane == 63) {
             sums[3 * (size_t)bm] = make_float4(w[0], w[1], w[2], w[3]);
             sums[3 * (size_t)bm + 1] = make_float4(w[4], w[5], w[6], w[7]);
-            sums[3 * (size_t)bm + 2] = make_float4(w[8], w[9], w[10], 0.0f);
+            sums[3 * (size_t)bm + 2] = make_float4(w[8], w[9], __int_as_float(wpix), 0.0f);
         }
     }
 }
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         grad_pc[3 * n] = gt[0]; grad_pc[3 * n + 1] = gt[1]; grad_pc[3 * n + 2] = gt[2];
         if (grad_uv) { grad_uv[2 * n] = guv0; grad_uv[2 * n + 1] = guv1; }
         if (mag) mag[n] = s[9];
-        if (n_affected) n_affected[m] = (int32_t)(s[10] + 0.5f);
+        if (n_affected) n_affected[m] = __float_as_int(s[10]);
         if (hook_gpc) { hook_gpc[3 * (size_t)m] = gt[0]; hook_gpc[3 * (size_t)m + 1] = gt[1]; hook_gpc[3 * (size_t)m + 2] = gt[2]; }
         if (hook_guv) { hook_guv[2 * (size_t)m] = guv0; hook_guv[2 * (size_t)m + 1] = guv1; }
         if (hook_mag) hook_mag[m] = s[9];
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         if (hook_depth) hook_depth[m] = GS_REC(PB, m).w;
         if (hook_uv) { const float4 pa = GS_REC(PA, m); hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
         if (c_num_in_camera) {                                          // GaussianPointAdaptiveController.update, CTRL:133-141
-            const int32_t npix = (int32_t)(s[10] + 0.5f);
+            const int32_t npix = __float_as_int(s[10]);
             c_num_in_camera[n] += 1;
             c_num_pixels[n] += npix;
             c_vs_grad[n] += s[9];
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256) void k_bwd_points(
     }
 }
 
-void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
+void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
         // workgroup 0 orders the tiles, the rest clear the flags + the shared all-zero row behind them (16-byte units)
@@ -618,12 +623,18 @@ void gs_launch_backward(const GsBackwardArgs& a, hipStream_t s)
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
+    if (a.M > 0 && a.T > 0 && a.K > 0)
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
+                                                                                  a.zero_row, a.sums));
+    else if (a.M > 0)
+        (void)hipMemsetAsync(a.sums, 0, sizeof(float) * PW * (size_t)a.M, s);          // no pairs at all: every sum is zero
+}
+
+void gs_launch_backward_points(const GsBackwardArgs& a, hipStream_t s)
+{
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) return;
     int keep = a.sh_band <= 0 ? 1 : a.sh_band == 1 ? 4 : a.sh_band == 2 ? 9 : 16;
-    if (a.M > 0)
-        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
-                                                                                  a.zero_row, a.sums));
     GS_TIMED(a.prof, KID_BWD_POINTS, s, k_bwd_points<<<nb, 256, 0, s>>>(a.N, a.cam_index, a.sums, a.PD, a.point_cloud, a.features,
                                                                     a.object_id, a.Kmat, a.pose, keep, a.f_color, a.f_high, a.f_s, a.f_q, a.f_alpha,
                                                                     a.grad_pc, a.grad_feat, a.grad_uv, a.mag, a.n_affected,

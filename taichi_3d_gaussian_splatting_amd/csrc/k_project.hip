@@ -1,6 +1,6 @@
 // k_project.hip -- per-point stages of the forward:
-//   k_pose_prepare   host prologue RAST:841-846 (inverse_SE3_qt_torch, UTIL:426-432) on device
-//   k_filter         filter_point_in_camera, RAST:31-78
+//   k_filter         filter_point_in_camera, RAST:31-78, with the host prologue RAST:841-846 (inverse_SE3_qt_torch,
+//                    UTIL:426-432) folded in: every block derives the pose records itself
 //   k_scan_tiles_publish   exclusive scan of the per-block tile counts (replaces the torch cumsum glue) + hand-over of M, K
 //   k_compact        point_id[mask], RAST:861-870 (ascending ids)
 //   k_project        generate_point_attributes_in_camera_plane RAST:239-315 fused with
@@ -57,16 +57,6 @@ __device__ __forceinline__ GsPose make_pose(const float* __restrict__ q_pc, cons
     return p;
 }
 
-// Host prologue of the reference (RAST:841-846) on the device: one pose record per object; also clears the
-// frame counters.  Launched alone only when the scene is empty; otherwise k_filter's first block does it.
-__global__ void k_pose_prepare(const float* __restrict__ q_pc, const float* __restrict__ t_pc, int n, GsPose* __restrict__ pose,
-                               GsCounters* __restrict__ counters)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { counters->M = 0; counters->K = 0; counters->max_depth_code = 0; counters->reserved = 0; }
-    if (i < n) pose[i] = make_pose(q_pc, t_pc, i);
-}
-
 // project_point_to_camera, GP3D:14-27 (T = [R|t; 0 0 0 1])
 __device__ __forceinline__ void project_point(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ Km,
                                               float x, float y, float z, float uv[2], float pc[3])
@@ -93,17 +83,21 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
     __shared__ GsPose sp[FILTER_POSE_CACHE];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // every block derives the (few) pose records itself -- same arithmetic as the stored ones -- so that no separate
-    // pose launch has to finish first; block 0 stores them for the later kernels and clears the frame counters
+    // pose launch has to finish first; block 0 stores them for the later kernels
     const bool cached = n_objects <= FILTER_POSE_CACHE;
     if (cached && threadIdx.x < n_objects) sp[threadIdx.x] = make_pose(q_pc, t_pc, threadIdx.x);
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) { counters->M = 0; counters->K = 0; counters->max_depth_code = 0; counters->reserved = 0; }
+    if (blockIdx.x == 0) {            // (the frame counters were reset by the previous frame's k_scan_tiles_publish)
         for (int o = threadIdx.x; o < n_objects; o += 256) pose[o] = make_pose(q_pc, t_pc, o);
     }
     __syncthreads();
     bool in = false;
-    if (i < N && invalid[i] != 1) {
-        const GsPose P = cached ? sp[obj[i]] : make_pose(q_pc, t_pc, obj[i]);
+    // an object id outside [0, n_objects) would index past the pose rows: such a row is left out and counted, and
+    // gs_forward reports it (the reference is unchecked here and reads whatever lies behind the array)
+    const int oid = (i < N && invalid[i] != 1) ? obj[i] : 0;
+    const bool bad_id = oid < 0 || oid >= n_objects;
+    if (bad_id) atomicAdd(&counters->bad_object_ids, 1);
+    if (i < N && invalid[i] != 1 && !bad_id) {
+        const GsPose P = cached ? sp[oid] : make_pose(q_pc, t_pc, oid);
         float Km[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Km[k] = Kmat[k];
@@ -291,6 +285,40 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
 
 
 // ---------------------------------------------------------------------------------
+// gs_forward_projected: the records arrive from elsewhere (another rank's k_project); what the binning needs besides
+// them -- tile box, tile count, per-block count sums, depth-code range -- is recomputed from u, v, radius and depth with
+// the same expressions k_project uses (RAST:81-128, 159-160), so the result is the one k_project would have stored.
+__global__ __launch_bounds__(256) void k_boxes_from_records(const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                            const float4* __restrict__ PD, int M, int W, int H, float depth_scale,
+                                                            ushort4* __restrict__ boxes, int32_t* __restrict__ ntiles,
+                                                            uint32_t* __restrict__ tile_block_sums, GsCounters* counters)
+{
+    __shared__ int wave_sum[4];
+    __shared__ int wave_max[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int count = 0, depth_code = 0;
+    if (idx < M) {
+        const float4 A = GS_REC(PA, idx);
+        int box[4];
+        gs_tile_box(A.x, A.y, GS_REC(PD, idx).w, (W + GS_TILE_SZ - 1) / GS_TILE_SZ, (H + GS_TILE_SZ - 1) / GS_TILE_SZ, box);
+        count = (box[1] - box[0]) * (box[3] - box[2]);
+        depth_code = (int)(GS_REC(PB, idx).w * depth_scale);
+        boxes[idx] = make_ushort4((unsigned short)box[0], (unsigned short)box[1], (unsigned short)box[2], (unsigned short)box[3]);
+        ntiles[idx] = count;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sm = gs_wave_sum_i(count), mx = gs_wave_max_i(depth_code);
+    if (lane == 0) { wave_sum[wave] = sm; wave_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_block_sums[blockIdx.x] = (uint32_t)(wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]);
+        const int m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+        if (m > 0) atomicMax(&counters->max_depth_code, m);
+        if (blockIdx.x == 0) counters->M = M;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Last kernel before the host has to know M, K and the depth-code range: exclusive scan of the per-block tile
 // counts (as k_scan_blocks), clear of the tile_start | tile_end | tile_work arrays (RAST:954-957 zero-init), and
 // publication of the frame counters straight into pinned host memory.  The host spins on `ticket` instead of
@@ -327,9 +355,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_publish(const uint32_t* __r
         host_mirror->M = counters->M;
         host_mirror->K = K;
         host_mirror->max_depth_code = counters->max_depth_code;
+        host_mirror->bad_object_ids = counters->bad_object_ids;
         __threadfence_system();
         host_mirror->reserved = ticket;              // the host waits for this value
         __threadfence_system();
+        // the accumulating counters start the next frame at zero (zero at gs_create for the first one): no clearing
+        // launch, and no block of the next k_filter / k_project can run ahead of a clear
+        counters->max_depth_code = 0;
+        counters->bad_object_ids = 0;
     }
 }
 
@@ -337,7 +370,6 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
 {
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) {
-        GS_TIMED(a.prof, KID_POSE, s, k_pose_prepare<<<(a.n_objects + 63) / 64, 64, 0, s>>>(a.q_pc, a.t_pc, a.n_objects, a.pose, a.counters));
         (void)hipMemsetAsync(a.tile_arrays, 0, sizeof(int32_t) * (size_t)a.tile_ints, s);     // empty scene: nothing else clears them
         return;
     }
@@ -348,6 +380,19 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters));
+    GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
+                                                                              a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
+}
+
+void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s)
+{
+    const int nb = (M + 255) / 256;
+    if (nb == 0) {
+        (void)hipMemsetAsync(a.tile_arrays, 0, sizeof(int32_t) * (size_t)a.tile_ints, s);
+        return;
+    }
+    GS_TIMED(a.prof, KID_PROJECT, s, k_boxes_from_records<<<nb, 256, 0, s>>>(a.PA, a.PB, a.PD, M, a.W, a.H, a.depth_scale, a.box, a.ntiles,
+                                                                          a.tile_block_sums, a.counters));
     GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
                                                                               a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
 }

@@ -27,7 +27,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"libgsrast.so does not export {n}"
     assert sorted(_native.SYMBOLS) == names
     assert L.gs_abi_version() == _native.ABI_VERSION
-    assert len(L.gs_kernel_names().decode().split(",")) == 16
+    # every name gs_kernel_names() lists is a kernel that exists in the sources (its position is its timing id)
+    kernels = L.gs_kernel_names().decode().split(",")
+    csrc = os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert len(kernels) == len(set(kernels)) == 15
+    for k in kernels:
+        assert re.search(r"__global__[^;{]*\b" + k + r"\s*\(", text), f"{k} is listed by gs_kernel_names() but is not a kernel"
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -287,7 +287,10 @@ def test_several_frames_in_flight_and_arena_is_stable(P):
         img.sum().backward()
         torch.cuda.synchronize()
         sizes.append(_native.lib().gs_ctx_device_bytes(ctx))
-    assert sizes[1:] == sizes[:-1], sizes
+    # a frame lives as long as its graph node (like the reference's saved tensors): o1 and o2 still pin two buffer sets,
+    # the loop needs one more on its first pass (the previous iteration's graph dies only when `img` is rebound) and
+    # nothing after that
+    assert sizes[2:] == sizes[1:-1], sizes
 
 
 def test_forward_without_backward_releases_its_frame(P):
