@@ -65,6 +65,15 @@ def main():
                          "BackwardValidPointHookInput payload; --no-hook measures the operator without one")
     ap.add_argument("--scene", default=None, help="a trained scene file (.parquet in the reference's layout or an INRIA .ply) to "
                     "render instead of the synthetic generator's points; camera and resolution still come from --workload")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="views each rank renders per step (gradients summed over them); a step then is V forward+backward passes "
+                         "and `value` counts views per second")
+    ap.add_argument("--reduce", choices=["step", "view"], default="step",
+                    help="view-parallel scheme with N > 1: 'step' = one all-reduce per step on the locally accumulated gradient; "
+                         "'view' = one asynchronous all-reduce per view, overlapped with the next view's forward+backward")
+    ap.add_argument("--scheme", choices=["view", "gaussian"], default="view",
+                    help="N > 1: 'view' = parameters replicated, gradient all-reduce; 'gaussian' = every rank owns 1/N of the Gaussians "
+                         "and renders one view, projected records and per-splat sums exchanged by two all-to-alls, no all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--breakdown-steps", type=int, default=10)
@@ -97,7 +106,9 @@ def main():
         scene.point_cloud, scene.point_cloud_features = pc_np, ft_np
         scene.point_invalid_mask = np.zeros(pc_np.shape[0], np.int8)
         scene.point_object_id = np.zeros(pc_np.shape[0], np.int32)
-    q, t = view_pose(rank, world)
+    V = max(1, args.views_per_rank)
+    n_views = world * V
+    q, t = view_pose(rank * V, n_views)
     H, W = scene.height, scene.width
     pc = torch.tensor(scene.point_cloud, device=dev, requires_grad=True)
     feat = torch.tensor(scene.point_cloud_features, device=dev, requires_grad=True)
@@ -118,18 +129,56 @@ def main():
 
     ncoll = []
     minus_one = torch.full((H, W, 3), -1.0, device=dev)
+    poses = [tuple(torch.tensor(x, device=dev) for x in view_pose(v, n_views)) for v in range(n_views)]
+    my_views = list(range(rank * V, rank * V + V))
+    reducer = gsd.OverlappedGradientReducer() if (world > 1 and args.reduce == "view" and args.scheme == "view") else None
+    gp_backend = None
+    gp_stats = {}
+    if args.scheme == "gaussian":
+        if mode != "fwdbwd" or V != 1:
+            raise SystemExit("--scheme gaussian runs forward+backward with one view per rank")
+        bounds = gsd.shard_bounds(pc.shape[0], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        shard_inp = Rast.GaussianPointCloudRasterisationInput(
+            point_cloud=pc.detach()[lo:hi].contiguous(), point_cloud_features=feat.detach()[lo:hi].contiguous(),
+            point_object_id=inp.point_object_id[lo:hi].contiguous(), point_invalid_mask=inp.point_invalid_mask[lo:hi].contiguous(),
+            camera_info=inp.camera_info, q_pointcloud_camera=poses[0][0], t_pointcloud_camera=poses[0][1], color_max_sh_band=3)
+        gp_backend = gsd.HipStageBackend(shard_inp, poses, rcfg)
+        module = gp_backend.st.module                  # the ctx the profiler reads
 
     def step():
+        if gp_backend is not None:
+            if world > 1:
+                _, _, _, st = gsd.gaussian_parallel_step(gp_backend, lambda img: torch.add(minus_one, img, alpha=2.0))
+            else:                                          # one rank: the same four stages chained, nothing to exchange
+                rec, h = gp_backend.project(0)
+                img, rh = gp_backend.render(rec)
+                sums = gp_backend.backward_render(rh, torch.add(minus_one, img, alpha=2.0))
+                gp_backend.backward_project(h, sums)
+                st = {"bytes_sent": 0, "collectives": 0}
+            gp_stats.update(st)
+            return
         if mode == "forward":
             with torch.no_grad():
-                module(inp)
+                for v in my_views:
+                    inp.q_pointcloud_camera, inp.t_pointcloud_camera = poses[v]
+                    module(inp)
             return
         pc.grad = None
         feat.grad = None
-        image, _, _ = module(inp)
-        g = torch.add(minus_one, image.detach(), alpha=2.0)   # dL/dimage of an MSE to mid-grey, 2*(image-0.5), one launch
-        image.backward(g)
-        if world > 1:
+        for v in my_views:
+            inp.q_pointcloud_camera, inp.t_pointcloud_camera = poses[v]
+            image, _, _ = module(inp)
+            g = torch.add(minus_one, image.detach(), alpha=2.0)   # dL/dimage of an MSE to mid-grey, 2*(image-0.5), one launch
+            image.backward(g)
+            if reducer is not None:
+                reducer.submit(pc.grad, feat.grad)                # asynchronous: runs beside the next view
+                pc.grad = None
+                feat.grad = None
+        if reducer is not None:
+            pc.grad, feat.grad = reducer.finish()
+            ncoll.append(V)
+        elif world > 1:
             ncoll.append(gsd.all_reduce_point_gradients(pc.grad, feat.grad))
 
     def sync_all():
@@ -154,13 +203,15 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     sync_all()
-    with torch.no_grad():                      # an inference call leaves a frame that can still be inspected
-        module(inp)
-    fr = module.last_frame
+    probe = Rast(rcfg)                           # an inference call leaves a frame that can still be inspected
+    inp.q_pointcloud_camera, inp.t_pointcloud_camera = poses[my_views[0]]
+    with torch.no_grad():
+        probe(inp)
+    fr = probe.last_frame
     M, K, T, key_bits = fr.n_points_in_camera, fr.n_keys, fr.n_tiles, fr.sort_key_bits
     N, P = pc.shape[0], H * W
     # evaluations the reference algorithm performs: every pixel walks its tile list up to its last effective entry
-    last = module.last_forward_outputs["pixel_offset_of_last_effective_point"].to(torch.int64)
+    last = probe.last_forward_outputs["pixel_offset_of_last_effective_point"].to(torch.int64)
     ty, tx = (H + 15) // 16, (W + 15) // 16
     tile_of_pixel = (torch.arange(H, device=dev) // 16)[:, None] * tx + (torch.arange(W, device=dev) // 16)[None, :]
     tstart = fr.export("tile_points_start").to(torch.int64)[tile_of_pixel]
@@ -205,25 +256,54 @@ def main():
                 traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dominant)
             except Exception:
                 traffic = None
+        # SQ counters of the same kernel (profiles/collect_sq.sh, a separate rocprofv3 --pmc pass): wave-level VALU instructions
+        # per launch against the SIMD-cycles of the launch measured live.  A wave64 FP32 instruction occupies its SIMD for 2
+        # cycles at full rate (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz), 4 for DPP / v_cmp /
+        # v_cndmask, 8 for v_exp / v_rcp / v_sqrt: cycles_per_valu_instruction near 2 means the vector ALUs are saturated.
+        valu = None
+        sq_path = os.path.join(ROOT, "profiles", "sq_counters.json")
+        if os.path.exists(sq_path) and avg_ms > 0:
+            try:
+                sq = json.load(open(sq_path))
+                if sq.get("workload") == args.workload and dominant in sq.get("kernels", {}):
+                    insts = sq["kernels"][dominant]["SQ_INSTS_VALU"]
+                    simd_cycles = avg_ms * 1e-3 * 2.4e9 * 1024
+                    valu = {"wave_valu_instructions_per_launch": insts, "simd_cycles_per_launch": round(simd_cycles),
+                            "cycles_per_valu_instruction": round(simd_cycles / insts, 3),
+                            "valu_busy_at_2_cycles_per_instruction": round(2.0 * insts / simd_cycles, 4),
+                            "source": "profiles/sq_counters.json (SQ_INSTS_VALU) / live HIP-event launch time, 2.4 GHz, 1024 SIMDs"}
+            except Exception:
+                valu = None
         fwd_bytes = 17 * N + 332 * M + 88 * K + 28 * P + 8 * T          # SURVEY 8d byte model
         bwd_bytes = (88 * K + 28 * P + 528 * M + 248 * N) if mode == "fwdbwd" else 0
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": ("fps fwd+bwd @1920x1080 (run as 1920x1088), 5e5 Gaussians" if args.workload == "cfg3_headline" and mode == "fwdbwd"
                        else f"fps {mode} {args.workload} @{W}x{H}, {N} Gaussians"),
-            "value": round(world * args.steps / elapsed, 2), "unit": "frames/s",
+            "value": round(world * V * args.steps / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "ms_per_view": round(ms_per_step / V, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic" if not args.scene else "file:" + os.path.basename(args.scene)),
             "config": {"workload": f"{args.workload}: synth(N={cfgw['N']}, {W}x{H}, sigma0={cfgw['sigma0']}, sh_deg={cfgw['sh_deg']}, seed 0), "
                                    f"{'fwd+bwd' if mode == 'fwdbwd' else 'forward only (torch.no_grad)'}, one view per GPU, sum all-reduce of 59*N f32 point gradients when N>1",
                        "points": N, "points_in_camera": M, "sort_pairs": K, "tiles": T, "sort_key_bits": key_bits,
                        "pixel_entry_evaluations": evals,
-                       "parallelism": f"view-parallel x{world}",
-                       "collectives_per_step": (ncoll[-1] if ncoll else 0), "rehearsal": rehearsal,
+                       "parallelism": (f"gaussian-parallel x{world}: 1/{world} of the Gaussians per rank, one view per rank, 2 all-to-alls"
+                                       if args.scheme == "gaussian" else
+                                       f"view-parallel x{world}, {V} view(s) per rank per step, all-reduce per {args.reduce}"),
+                       "views_per_rank": V, "views_per_step": world * V,
+                       "collectives_per_step": (gp_stats.get("collectives", 0) if args.scheme == "gaussian" else (ncoll[-1] if ncoll else 0)),
+                       "exchange_bytes_sent_per_rank_per_step": (gp_stats.get("bytes_sent") if args.scheme == "gaussian"
+                                                                 else (0 if world == 1 else 236 * N * (V if args.reduce == "view" else 1))),
+                       "rehearsal": rehearsal,
                        "backward_hook": bool(args.hook)},
-            "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+            "roofline": {"kernel": dominant, "bound": bound,
+                         "bound_detail": ("FP32 vector ALU (no MFMA anywhere on this path: there is no dense contraction); the schema's "
+                                          "'mfma' slot is used because 157.3 TFLOP/s is both the f32 vector and the f32 MFMA dense peak; "
+                                          "`achieved` counts the reference algorithm's flops per evaluation, not issued instructions"
+                                          if bound == "mfma" else "HBM bandwidth"),
+                         "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "valu": valu,
                          "avg_launch_ms": round(avg_ms, 4), "launches": dom[1], "model": KERNEL_MODEL_DOC},
             "frame_hbm": {"algorithmic_bytes": fwd_bytes + bwd_bytes,
                           "achieved_GBps": round((fwd_bytes + bwd_bytes) / (ms_per_step * 1e-3) / 1e9, 1),

@@ -431,94 +431,11 @@ int gso_num_threads(void)
 #endif
 }
 
-gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, const int32_t* obj,
-                       int64_t N, const float* q_pc, const float* t_pc, int32_t n_obj,
-                       const float* Km, int32_t H, int32_t W, const gso_config* cfg)
+/* ---- per-pixel half of the forward: tile counts are already there; scan, keys, sort, ranges, blend ---- */
+static void raster_stage(gso_frame* f, const gso_config* cfg)
 {
-    if (W <= 0 || H <= 0 || n_obj <= 0) return NULL;
-    if (!cfg->allow_partial_tiles && (W % GSO_TILE != 0 || H % GSO_TILE != 0)) return NULL;  /* RAST:1193-1194 */
-    gso_frame* f = (gso_frame*)zalloc(sizeof(gso_frame));
-    f->N = N; f->H = H; f->W = W; f->n_objects = n_obj;
-    f->tiles_x = (W + GSO_TILE - 1) / GSO_TILE; f->tiles_y = (H + GSO_TILE - 1) / GSO_TILE;   /* = W/16, H/16 for the reference's sizes */
-    f->T = f->tiles_x * f->tiles_y;
-    f->q_camera_pointcloud = (float*)zalloc(sizeof(float) * 4 * n_obj);
-    f->t_camera_pointcloud = (float*)zalloc(sizeof(float) * 3 * n_obj);
-    gso_inverse_se3_qt(q_pc, t_pc, n_obj, f->q_camera_pointcloud, f->t_camera_pointcloud); /* RAST:845 */
-
-    /* ---- step 1: filter_point_in_camera, RAST:31-78 ---- */
-    f->point_in_camera_mask = (int8_t*)zalloc((size_t)N);
-    const float near_plane = cfg->near_plane, far_plane = cfg->far_plane;
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < N; ++i) {
-        if (invalid[i] == 1) { f->point_in_camera_mask[i] = 0; continue; }
-        float T[16], uv[2], pcam[3];
-        transform_from_qt(f->q_camera_pointcloud + 4 * obj[i], f->t_camera_pointcloud + 3 * obj[i], T);
-        project_point_to_camera(pc + 3 * i, T, Km, uv, pcam);
-        float z = pcam[2];
-        int in = z > near_plane && z < far_plane &&
-                 uv[0] >= (float)(-GSO_TILE * GSO_BOUNDARY_TILES) &&
-                 uv[0] < (float)(W + GSO_TILE * GSO_BOUNDARY_TILES) &&
-                 uv[1] >= (float)(-GSO_TILE * GSO_BOUNDARY_TILES) &&
-                 uv[1] < (float)(H + GSO_TILE * GSO_BOUNDARY_TILES);
-        f->point_in_camera_mask[i] = in ? 1 : 0;
-    }
-    /* ---- compaction, RAST:861-870 (ascending ids) ---- */
-    int64_t M = 0;
-    for (int64_t i = 0; i < N; ++i) M += f->point_in_camera_mask[i];
-    f->M = M;
-    f->point_id_in_camera_list = (int32_t*)zalloc(sizeof(int32_t) * (size_t)M);
-    { int64_t m = 0; for (int64_t i = 0; i < N; ++i) if (f->point_in_camera_mask[i]) f->point_id_in_camera_list[m++] = (int32_t)i; }
-
-    f->point_uv = (float*)zalloc(sizeof(float) * 2 * (size_t)M);
-    f->point_in_camera = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
-    f->point_uv_conic_and_rescale = (float*)zalloc(sizeof(float) * 4 * (size_t)M);
-    f->point_alpha_after_activation = (float*)zalloc(sizeof(float) * (size_t)M);
-    f->point_color = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
-    f->point_radii = (float*)zalloc(sizeof(float) * (size_t)M);
-    f->num_overlap_tiles = (int32_t*)zalloc(sizeof(int32_t) * (size_t)M);
-    f->accumulated_num_overlap_tiles = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
-
-    /* ---- step 2: generate_point_attributes_in_camera_plane, RAST:239-315 ---- */
-#pragma omp parallel for schedule(static)
-    for (int64_t idx = 0; idx < M; ++idx) {
-        int32_t pid = f->point_id_in_camera_list[idx];
-        float* row = feat + (size_t)GSO_FEAT * pid;
-        /* RAST:196-205 normalise the rotation quaternion in place */
-        {
-            float n = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2] + row[3] * row[3]);
-            row[0] = row[0] / n; row[1] = row[1] / n; row[2] = row[2] / n; row[3] = row[3] / n;
-        }
-        const float* xyz = pc + 3 * (size_t)pid;
-        float T[16], ray_origin[3];
-        transform_from_qt(f->q_camera_pointcloud + 4 * obj[pid], f->t_camera_pointcloud + 3 * obj[pid], T);
-        inverse_se3_translation(T, ray_origin);                       /* RAST:280-282 */
-        float uv[2], pcam[3], cov[4], conic[4];
-        project_point_to_camera(xyz, T, Km, uv, pcam);               /* RAST:284-287 */
-        gso_project_to_camera_covariance(row, row + 4, T, Km, pcam, cov); /* RAST:288-292 */
-        gso_conic_and_rescale(cov, conic);                            /* RAST:293 */
-        f->point_uv[2 * idx] = uv[0]; f->point_uv[2 * idx + 1] = uv[1];
-        f->point_in_camera[3 * idx] = pcam[0]; f->point_in_camera[3 * idx + 1] = pcam[1]; f->point_in_camera[3 * idx + 2] = pcam[2];
-        memcpy(f->point_uv_conic_and_rescale + 4 * idx, conic, sizeof conic);
-        f->point_alpha_after_activation[idx] = 1.0f / (1.0f + gso_expf(-row[7]));  /* RAST:299-300 */
-        float dir[3] = { xyz[0] - ray_origin[0], xyz[1] - ray_origin[1], xyz[2] - ray_origin[2] };
-        float sh[16];
-        gso_spherical_harmonics(dir, sh);
-        f->point_color[3 * idx + 0] = sigmoidf_(dot16(row + 8, sh));   /* GP3D:333-349 */
-        f->point_color[3 * idx + 1] = sigmoidf_(dot16(row + 24, sh));
-        f->point_color[3 * idx + 2] = sigmoidf_(dot16(row + 40, sh));
-        /* RAST:311-315: radius from the covariance as the caller still holds it.
-         * Taichi passes the mat2 to get_point_conic_and_rescale by value, so the
-         * +0.3 blur does not leak back (switch kept for the open point in SURVEY 8a). */
-        float c00 = cov[0], c01 = cov[1], c10 = cov[2], c11 = cov[3];
-        if (!cfg->radius_from_preblur_cov) { c00 = c00 + 0.3f; c11 = c11 + 0.3f; }
-        float large_eigen = (c00 + c11 + sqrtf((c00 - c11) * (c00 - c11) + 4.0f * c01 * c10)) / 2.0f;
-        float radii = sqrtf(large_eigen) * 3.0f;
-        f->point_radii[idx] = radii;
-        /* ---- step 3: generate_num_overlap_tiles, RAST:106-128 ---- */
-        int32_t box[4];
-        bounding_box_tiles(uv[0], uv[1], radii, f->tiles_x, f->tiles_y, box);
-        f->num_overlap_tiles[idx] = (box[1] - box[0]) * (box[3] - box[2]);
-    }
+    const int64_t M = f->M;
+    const int32_t H = f->H, W = f->W;
     /* RAST:913-922 exclusive scan */
     int64_t K = 0;
     for (int64_t i = 0; i < M; ++i) { f->accumulated_num_overlap_tiles[i] = K; K += f->num_overlap_tiles[i]; }
@@ -607,6 +524,150 @@ gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, cons
             }
         }
     }
+}
+
+gso_frame* gso_forward(const float* pc, float* feat, const int8_t* invalid, const int32_t* obj,
+                       int64_t N, const float* q_pc, const float* t_pc, int32_t n_obj,
+                       const float* Km, int32_t H, int32_t W, const gso_config* cfg)
+{
+    if (W <= 0 || H <= 0 || n_obj <= 0) return NULL;
+    if (!cfg->allow_partial_tiles && (W % GSO_TILE != 0 || H % GSO_TILE != 0)) return NULL;  /* RAST:1193-1194 */
+    gso_frame* f = (gso_frame*)zalloc(sizeof(gso_frame));
+    f->N = N; f->H = H; f->W = W; f->n_objects = n_obj;
+    f->tiles_x = (W + GSO_TILE - 1) / GSO_TILE; f->tiles_y = (H + GSO_TILE - 1) / GSO_TILE;   /* = W/16, H/16 for the reference's sizes */
+    f->T = f->tiles_x * f->tiles_y;
+    f->q_camera_pointcloud = (float*)zalloc(sizeof(float) * 4 * n_obj);
+    f->t_camera_pointcloud = (float*)zalloc(sizeof(float) * 3 * n_obj);
+    gso_inverse_se3_qt(q_pc, t_pc, n_obj, f->q_camera_pointcloud, f->t_camera_pointcloud); /* RAST:845 */
+
+    /* ---- step 1: filter_point_in_camera, RAST:31-78 ---- */
+    f->point_in_camera_mask = (int8_t*)zalloc((size_t)N);
+    const float near_plane = cfg->near_plane, far_plane = cfg->far_plane;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        if (invalid[i] == 1) { f->point_in_camera_mask[i] = 0; continue; }
+        float T[16], uv[2], pcam[3];
+        transform_from_qt(f->q_camera_pointcloud + 4 * obj[i], f->t_camera_pointcloud + 3 * obj[i], T);
+        project_point_to_camera(pc + 3 * i, T, Km, uv, pcam);
+        float z = pcam[2];
+        int in = z > near_plane && z < far_plane &&
+                 uv[0] >= (float)(-GSO_TILE * GSO_BOUNDARY_TILES) &&
+                 uv[0] < (float)(W + GSO_TILE * GSO_BOUNDARY_TILES) &&
+                 uv[1] >= (float)(-GSO_TILE * GSO_BOUNDARY_TILES) &&
+                 uv[1] < (float)(H + GSO_TILE * GSO_BOUNDARY_TILES);
+        f->point_in_camera_mask[i] = in ? 1 : 0;
+    }
+    /* ---- compaction, RAST:861-870 (ascending ids) ---- */
+    int64_t M = 0;
+    for (int64_t i = 0; i < N; ++i) M += f->point_in_camera_mask[i];
+    f->M = M;
+    f->point_id_in_camera_list = (int32_t*)zalloc(sizeof(int32_t) * (size_t)M);
+    { int64_t m = 0; for (int64_t i = 0; i < N; ++i) if (f->point_in_camera_mask[i]) f->point_id_in_camera_list[m++] = (int32_t)i; }
+
+    f->point_uv = (float*)zalloc(sizeof(float) * 2 * (size_t)M);
+    f->point_in_camera = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
+    f->point_uv_conic_and_rescale = (float*)zalloc(sizeof(float) * 4 * (size_t)M);
+    f->point_alpha_after_activation = (float*)zalloc(sizeof(float) * (size_t)M);
+    f->point_color = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
+    f->point_radii = (float*)zalloc(sizeof(float) * (size_t)M);
+    f->num_overlap_tiles = (int32_t*)zalloc(sizeof(int32_t) * (size_t)M);
+    f->accumulated_num_overlap_tiles = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
+
+    /* ---- step 2: generate_point_attributes_in_camera_plane, RAST:239-315 ---- */
+#pragma omp parallel for schedule(static)
+    for (int64_t idx = 0; idx < M; ++idx) {
+        int32_t pid = f->point_id_in_camera_list[idx];
+        float* row = feat + (size_t)GSO_FEAT * pid;
+        /* RAST:196-205 normalise the rotation quaternion in place */
+        {
+            float n = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2] + row[3] * row[3]);
+            row[0] = row[0] / n; row[1] = row[1] / n; row[2] = row[2] / n; row[3] = row[3] / n;
+        }
+        const float* xyz = pc + 3 * (size_t)pid;
+        float T[16], ray_origin[3];
+        transform_from_qt(f->q_camera_pointcloud + 4 * obj[pid], f->t_camera_pointcloud + 3 * obj[pid], T);
+        inverse_se3_translation(T, ray_origin);                       /* RAST:280-282 */
+        float uv[2], pcam[3], cov[4], conic[4];
+        project_point_to_camera(xyz, T, Km, uv, pcam);               /* RAST:284-287 */
+        gso_project_to_camera_covariance(row, row + 4, T, Km, pcam, cov); /* RAST:288-292 */
+        gso_conic_and_rescale(cov, conic);                            /* RAST:293 */
+        f->point_uv[2 * idx] = uv[0]; f->point_uv[2 * idx + 1] = uv[1];
+        f->point_in_camera[3 * idx] = pcam[0]; f->point_in_camera[3 * idx + 1] = pcam[1]; f->point_in_camera[3 * idx + 2] = pcam[2];
+        memcpy(f->point_uv_conic_and_rescale + 4 * idx, conic, sizeof conic);
+        f->point_alpha_after_activation[idx] = 1.0f / (1.0f + gso_expf(-row[7]));  /* RAST:299-300 */
+        float dir[3] = { xyz[0] - ray_origin[0], xyz[1] - ray_origin[1], xyz[2] - ray_origin[2] };
+        float sh[16];
+        gso_spherical_harmonics(dir, sh);
+        f->point_color[3 * idx + 0] = sigmoidf_(dot16(row + 8, sh));   /* GP3D:333-349 */
+        f->point_color[3 * idx + 1] = sigmoidf_(dot16(row + 24, sh));
+        f->point_color[3 * idx + 2] = sigmoidf_(dot16(row + 40, sh));
+        /* RAST:311-315: radius from the covariance as the caller still holds it.
+         * Taichi passes the mat2 to get_point_conic_and_rescale by value, so the
+         * +0.3 blur does not leak back (switch kept for the open point in SURVEY 8a). */
+        float c00 = cov[0], c01 = cov[1], c10 = cov[2], c11 = cov[3];
+        if (!cfg->radius_from_preblur_cov) { c00 = c00 + 0.3f; c11 = c11 + 0.3f; }
+        float large_eigen = (c00 + c11 + sqrtf((c00 - c11) * (c00 - c11) + 4.0f * c01 * c10)) / 2.0f;
+        float radii = sqrtf(large_eigen) * 3.0f;
+        f->point_radii[idx] = radii;
+        /* ---- step 3: generate_num_overlap_tiles, RAST:106-128 ---- */
+        int32_t box[4];
+        bounding_box_tiles(uv[0], uv[1], radii, f->tiles_x, f->tiles_y, box);
+        f->num_overlap_tiles[idx] = (box[1] - box[0]) * (box[3] - box[2]);
+    }
+    raster_stage(f, cfg);
+    return f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* The same path cut at the projected records (test stand-in for the staged   */
+/* entry points of libgsrast: gs_project_shard / gs_forward_projected /       */
+/* gs_backward_projected / gs_backward_shard, include/gs_rasterizer.h).       */
+/* A record = the per-point arrays of RAST:873-911 for one in-camera point:   */
+/* u v conic_a conic_b | conic_c rescale opacity depth | r g b (unused) | x y z(camera) radius */
+/* ------------------------------------------------------------------------- */
+void gso_pack_records(const gso_frame* f, float* out)
+{
+    for (int64_t i = 0; i < f->M; ++i) {
+        float* r = out + 16 * i;
+        const float* cn = f->point_uv_conic_and_rescale + 4 * i;
+        r[0] = f->point_uv[2 * i]; r[1] = f->point_uv[2 * i + 1]; r[2] = cn[0]; r[3] = cn[1];
+        r[4] = cn[2]; r[5] = cn[3]; r[6] = f->point_alpha_after_activation[i]; r[7] = f->point_in_camera[3 * i + 2];
+        r[8] = f->point_color[3 * i]; r[9] = f->point_color[3 * i + 1]; r[10] = f->point_color[3 * i + 2]; r[11] = 0.0f;
+        r[12] = f->point_in_camera[3 * i]; r[13] = f->point_in_camera[3 * i + 1]; r[14] = f->point_in_camera[3 * i + 2];
+        r[15] = f->point_radii[i];
+    }
+}
+
+gso_frame* gso_forward_from_projected(int64_t M, const float* records, int32_t H, int32_t W, const gso_config* cfg)
+{
+    if (W <= 0 || H <= 0 || M < 0) return NULL;
+    if (!cfg->allow_partial_tiles && (W % GSO_TILE != 0 || H % GSO_TILE != 0)) return NULL;
+    gso_frame* f = (gso_frame*)zalloc(sizeof(gso_frame));
+    f->N = M; f->M = M; f->H = H; f->W = W; f->n_objects = 0;
+    f->tiles_x = (W + GSO_TILE - 1) / GSO_TILE; f->tiles_y = (H + GSO_TILE - 1) / GSO_TILE;
+    f->T = f->tiles_x * f->tiles_y;
+    f->point_uv = (float*)zalloc(sizeof(float) * 2 * (size_t)M);
+    f->point_in_camera = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
+    f->point_uv_conic_and_rescale = (float*)zalloc(sizeof(float) * 4 * (size_t)M);
+    f->point_alpha_after_activation = (float*)zalloc(sizeof(float) * (size_t)M);
+    f->point_color = (float*)zalloc(sizeof(float) * 3 * (size_t)M);
+    f->point_radii = (float*)zalloc(sizeof(float) * (size_t)M);
+    f->num_overlap_tiles = (int32_t*)zalloc(sizeof(int32_t) * (size_t)M);
+    f->accumulated_num_overlap_tiles = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
+    for (int64_t i = 0; i < M; ++i) {
+        const float* r = records + 16 * i;
+        f->point_uv[2 * i] = r[0]; f->point_uv[2 * i + 1] = r[1];
+        float* cn = f->point_uv_conic_and_rescale + 4 * i;
+        cn[0] = r[2]; cn[1] = r[3]; cn[2] = r[4]; cn[3] = r[5];
+        f->point_alpha_after_activation[i] = r[6];
+        f->point_color[3 * i] = r[8]; f->point_color[3 * i + 1] = r[9]; f->point_color[3 * i + 2] = r[10];
+        f->point_in_camera[3 * i] = r[12]; f->point_in_camera[3 * i + 1] = r[13]; f->point_in_camera[3 * i + 2] = r[14];
+        f->point_radii[i] = r[15];
+        int32_t box[4];
+        bounding_box_tiles(r[0], r[1], r[15], f->tiles_x, f->tiles_y, box);          /* RAST:106-128 */
+        f->num_overlap_tiles[i] = (box[1] - box[0]) * (box[3] - box[2]);
+    }
+    raster_stage(f, cfg);
     return f;
 }
 
@@ -627,33 +688,14 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
  * absolute values of the loop-1 contributions (RAST:674-696), carried through the absolute values of the loop-2
  * Jacobians and the grad factors.  A float accumulation can only be judged against that magnitude (an element whose
  * terms cancel has no relative accuracy to speak of); the parity tests use it as the floor of their per-element bar. */
-int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, const int32_t* obj,
-                    const float* q_pc, const float* t_pc, const float* Km,
-                    const float* grad_image, int32_t sh_band, const gso_config* cfg,
-                    float* g_pc, float* g_feat, float* g_uv, float* mag, float* mag_img,
-                    int32_t* n_affected, float* out_cov_buf, float* out_color_buf,
-                    float* summed_pc, float* summed_feat)
-{
-    (void)q_pc;
-    const int64_t N = f->N, M = f->M;
-    const int32_t W = f->W;
-    memset(g_pc, 0, sizeof(float) * 3 * (size_t)N);           /* RAST:1051-1058 */
-    memset(g_feat, 0, sizeof(float) * GSO_FEAT * (size_t)N);
-    memset(g_uv, 0, sizeof(float) * 2 * (size_t)N);
-    memset(mag, 0, sizeof(float) * (size_t)N);
-    memset(n_affected, 0, sizeof(int32_t) * (size_t)M);
-    /* double accumulators stand in for ti.atomic_add (RAST:674-696) */
-    double* a_uv = (double*)zalloc(sizeof(double) * 2 * (size_t)M);
-    double* a_cov = (double*)zalloc(sizeof(double) * 3 * (size_t)M);
-    double* a_col = (double*)zalloc(sizeof(double) * 3 * (size_t)M);
-    double* a_alpha = (double*)zalloc(sizeof(double) * (size_t)M);
-    double* a_mag = (double*)zalloc(sizeof(double) * (size_t)M);
-    int64_t* a_cnt = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
-    /* sums of |contribution|: uv 0..1, cov 2..4, colour 5..7, opacity 8 */
-    double* a_abs = summed_pc || summed_feat ? (double*)zalloc(sizeof(double) * 9 * (size_t)M) : NULL;
-    if (summed_pc) memset(summed_pc, 0, sizeof(float) * 3 * (size_t)N);
-    if (summed_feat) memset(summed_feat, 0, sizeof(float) * GSO_FEAT * (size_t)N);
+/* loop 1 (RAST:531-705) into the reference's accumulators; doubles stand in for ti.atomic_add (RAST:674-696) */
+typedef struct { double *a_uv, *a_cov, *a_col, *a_alpha, *a_mag, *a_abs; int64_t* a_cnt; } gso_acc;
 
+static void backward_loop1(const gso_frame* f, const float* grad_image, float* mag_img, gso_acc acc)
+{
+    const int32_t W = f->W;
+    double *a_uv = acc.a_uv, *a_cov = acc.a_cov, *a_col = acc.a_col, *a_alpha = acc.a_alpha, *a_mag = acc.a_mag, *a_abs = acc.a_abs;
+    int64_t* a_cnt = acc.a_cnt;
     /* ---- loop 1, RAST:531-705; tiles in parallel, sums via atomic double adds ---- */
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t tile_id = 0; tile_id < f->T; ++tile_id) {
@@ -745,6 +787,55 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
             mag_img[2 * o] = tot0; mag_img[2 * o + 1] = tot1;    /* RAST:700-704 */
         }
     }
+}
+
+/* the accumulators as one float row per in-camera point -- the tensors the reference hands from loop 1 to loop 2
+ * (grad_uv, the cov / colour buffers, opacity gradient, magnitude, pixel count), rounded to f32 exactly where
+ * RAST:716-721 reads them: d uv (2) | d cov xx xy yy (3) | d colour (3) | d opacity | sum |d uv| | count (i32 bits) | 0 */
+static void pack_sums(int64_t M, gso_acc acc, float* sums)
+{
+    for (int64_t i = 0; i < M; ++i) {
+        float* r = sums + 12 * i;
+        r[0] = (float)acc.a_uv[2 * i]; r[1] = (float)acc.a_uv[2 * i + 1];
+        r[2] = (float)acc.a_cov[3 * i]; r[3] = (float)acc.a_cov[3 * i + 1]; r[4] = (float)acc.a_cov[3 * i + 2];
+        r[5] = (float)acc.a_col[3 * i]; r[6] = (float)acc.a_col[3 * i + 1]; r[7] = (float)acc.a_col[3 * i + 2];
+        r[8] = (float)acc.a_alpha[i]; r[9] = (float)acc.a_mag[i];
+        int32_t cnt = (int32_t)acc.a_cnt[i];
+        memcpy(r + 10, &cnt, sizeof cnt);
+        r[11] = 0.0f;
+    }
+}
+
+static gso_acc acc_alloc(int64_t M, int with_abs)
+{
+    gso_acc a;
+    a.a_uv = (double*)zalloc(sizeof(double) * 2 * (size_t)M);
+    a.a_cov = (double*)zalloc(sizeof(double) * 3 * (size_t)M);
+    a.a_col = (double*)zalloc(sizeof(double) * 3 * (size_t)M);
+    a.a_alpha = (double*)zalloc(sizeof(double) * (size_t)M);
+    a.a_mag = (double*)zalloc(sizeof(double) * (size_t)M);
+    a.a_cnt = (int64_t*)zalloc(sizeof(int64_t) * (size_t)M);
+    a.a_abs = with_abs ? (double*)zalloc(sizeof(double) * 9 * (size_t)M) : NULL;   /* sums of |products|: uv 0..1, cov 2..4, colour 5..7, opacity 8 */
+    return a;
+}
+
+static void acc_free(gso_acc a) { free(a.a_uv); free(a.a_cov); free(a.a_col); free(a.a_alpha); free(a.a_mag); free(a.a_cnt); free(a.a_abs); }
+
+/* loop 2 (RAST:708-772) + masking/scaling (RAST:1102-1125) from the packed rows.  `f` supplies the per-point arrays of
+ * the shard whose rows these are (ids, point_in_camera, camera pose); N rows of gradients are fully written. */
+static void backward_loop2(const gso_frame* f, const float* pc, const float* feat, const int32_t* obj, const float* t_pc,
+                           const float* Km, const float* sums, const double* a_abs, int32_t sh_band, const gso_config* cfg,
+                           float* g_pc, float* g_feat, float* g_uv, float* mag, int32_t* n_affected,
+                           float* out_cov_buf, float* out_color_buf, float* summed_pc, float* summed_feat)
+{
+    const int64_t N = f->N, M = f->M;
+    memset(g_pc, 0, sizeof(float) * 3 * (size_t)N);           /* RAST:1051-1058 */
+    memset(g_feat, 0, sizeof(float) * GSO_FEAT * (size_t)N);
+    memset(g_uv, 0, sizeof(float) * 2 * (size_t)N);
+    memset(mag, 0, sizeof(float) * (size_t)N);
+    memset(n_affected, 0, sizeof(int32_t) * (size_t)M);
+    if (summed_pc) memset(summed_pc, 0, sizeof(float) * 3 * (size_t)N);
+    if (summed_feat) memset(summed_feat, 0, sizeof(float) * GSO_FEAT * (size_t)N);
     /* ---- loop 2, RAST:708-772, then masking/scaling RAST:1102-1125 ---- */
     int keep = sh_band <= 0 ? 1 : sh_band == 1 ? 4 : sh_band == 2 ? 9 : 16;  /* RAST:1167-1182 */
 #pragma omp parallel for schedule(static)
@@ -752,10 +843,11 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
         int32_t pid = f->point_id_in_camera_list[idx];
         const float* row = feat + (size_t)GSO_FEAT * pid;
         const float* xyz = pc + 3 * (size_t)pid;
-        float guv[2] = { (float)a_uv[2 * idx], (float)a_uv[2 * idx + 1] };
-        float gc0 = (float)a_cov[3 * idx], gc1 = (float)a_cov[3 * idx + 1], gc2 = (float)a_cov[3 * idx + 2];
+        const float* row12 = sums + 12 * (size_t)idx;
+        float guv[2] = { row12[0], row12[1] };
+        float gc0 = row12[2], gc1 = row12[3], gc2 = row12[4];
         float gcov[4] = { gc0, gc1, gc1, gc2 };                 /* RAST:716-721 */
-        float gcol[3] = { (float)a_col[3 * idx], (float)a_col[3 * idx + 1], (float)a_col[3 * idx + 2] };
+        float gcol[3] = { row12[5], row12[6], row12[7] };
         float T[16];
         transform_from_qt(f->q_camera_pointcloud + 4 * obj[pid], f->t_camera_pointcloud + 3 * obj[pid], T);
         const float* ray_origin = t_pc + 3 * obj[pid];          /* RAST:731-732 */
@@ -779,7 +871,7 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
         gp[0] = gt[0]; gp[1] = gt[1]; gp[2] = gt[2];
         for (int i = 0; i < 4; ++i) gf[i] = gq[i] * cfg->grad_q_factor;
         for (int i = 0; i < 3; ++i) gf[4 + i] = gs[i] * cfg->grad_s_factor;
-        gf[7] = (float)a_alpha[idx] * cfg->grad_alpha_factor;
+        gf[7] = row12[8] * cfg->grad_alpha_factor;
         for (int ch = 0; ch < 3; ++ch)
             for (int i = 0; i < 16; ++i) {
                 float v = gcol[ch] * (jac[ch] * sh[i]);          /* RAST:754-756, GP3D:368-370 */
@@ -812,11 +904,48 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
             }
         }
         g_uv[2 * (size_t)pid] = guv[0]; g_uv[2 * (size_t)pid + 1] = guv[1];
-        mag[pid] = (float)a_mag[idx];
-        n_affected[idx] = (int32_t)a_cnt[idx];
+        mag[pid] = row12[9];
+        { int32_t cnt; memcpy(&cnt, row12 + 10, sizeof cnt); n_affected[idx] = cnt; }
         if (out_cov_buf) { out_cov_buf[3 * idx] = gc0; out_cov_buf[3 * idx + 1] = gc1; out_cov_buf[3 * idx + 2] = gc2; }
         if (out_color_buf) { out_color_buf[3 * idx] = gcol[0]; out_color_buf[3 * idx + 1] = gcol[1]; out_color_buf[3 * idx + 2] = gcol[2]; }
     }
-    free(a_uv); free(a_cov); free(a_col); free(a_alpha); free(a_mag); free(a_cnt); free(a_abs);
+}
+
+int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, const int32_t* obj,
+                    const float* q_pc, const float* t_pc, const float* Km,
+                    const float* grad_image, int32_t sh_band, const gso_config* cfg,
+                    float* g_pc, float* g_feat, float* g_uv, float* mag, float* mag_img,
+                    int32_t* n_affected, float* out_cov_buf, float* out_color_buf,
+                    float* summed_pc, float* summed_feat)
+{
+    (void)q_pc;
+    const int64_t M = f->M;
+    gso_acc acc = acc_alloc(M, summed_pc || summed_feat);
+    backward_loop1(f, grad_image, mag_img, acc);
+    float* sums = (float*)zalloc(sizeof(float) * 12 * (size_t)M);
+    pack_sums(M, acc, sums);
+    backward_loop2(f, pc, feat, obj, t_pc, Km, sums, acc.a_abs, sh_band, cfg, g_pc, g_feat, g_uv, mag, n_affected,
+                   out_cov_buf, out_color_buf, summed_pc, summed_feat);
+    free(sums);
+    acc_free(acc);
     return 0;
 }
+
+/* ---- the two halves on their own (stand-ins for gs_backward_projected / gs_backward_shard) ---- */
+int gso_backward_sums(const gso_frame* f, const float* grad_image, float* sums, float* mag_img)
+{
+    gso_acc acc = acc_alloc(f->M, 0);
+    backward_loop1(f, grad_image, mag_img, acc);
+    pack_sums(f->M, acc, sums);
+    acc_free(acc);
+    return 0;
+}
+
+int gso_backward_points(const gso_frame* f, const float* pc, const float* feat, const int32_t* obj, const float* t_pc,
+                        const float* Km, const float* sums, int32_t sh_band, const gso_config* cfg,
+                        float* g_pc, float* g_feat, float* g_uv, float* mag, int32_t* n_affected)
+{
+    backward_loop2(f, pc, feat, obj, t_pc, Km, sums, NULL, sh_band, cfg, g_pc, g_feat, g_uv, mag, n_affected, NULL, NULL, NULL, NULL);
+    return 0;
+}
+

@@ -163,6 +163,20 @@ int gso_backward_ex(const gso_frame* f,
                     float* grad_uv_cov_buffer, float* grad_color_buffer,
                     float* summed_pointcloud, float* summed_pointcloud_features);
 
+/* ---- the same path cut at the projected records and at the per-point sums: stand-ins, on the CPU, for the staged entry
+ * points of the library under test (gs_project_shard / gs_forward_projected / gs_backward_projected / gs_backward_shard).
+ * Records: 16 floats per in-camera point (layout in gs_oracle.c); sums: 12 floats per in-camera point = the reference's
+ * loop-1 accumulators (post-factor, unlike the library's rows -- each half is only ever paired with its own other half). */
+void gso_pack_records(const gso_frame* f, float* records_out);                 /* (M,16) from any frame */
+gso_frame* gso_forward_from_projected(int64_t M, const float* records, int32_t H, int32_t W, const gso_config* cfg);
+int gso_backward_sums(const gso_frame* f, const float* grad_rasterized_image, float* sums_out /* (M,12) */,
+                      float* magnitude_grad_viewspace_on_image /* (H,W,2) */);
+int gso_backward_points(const gso_frame* f /* the shard's own forward frame */, const float* point_cloud,
+                        const float* point_cloud_features, const int32_t* point_object_id, const float* t_pointcloud_camera,
+                        const float* camera_intrinsics, const float* sums /* (M,12) */, int32_t color_max_sh_band,
+                        const gso_config* cfg, float* grad_pointcloud, float* grad_pointcloud_features,
+                        float* grad_viewspace, float* magnitude_grad_viewspace, int32_t* num_affected_pixels);
+
 void gso_frame_free(gso_frame* f);
 int  gso_num_threads(void);
 

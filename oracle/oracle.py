@@ -83,6 +83,14 @@ def lib():
         L.gso_backward.argtypes = [C.POINTER(_Frame)] + [C.c_void_p] * 7 + [C.c_int32, C.POINTER(Config)] + [C.c_void_p] * 8
         L.gso_backward_ex.restype = C.c_int
         L.gso_backward_ex.argtypes = [C.POINTER(_Frame)] + [C.c_void_p] * 7 + [C.c_int32, C.POINTER(Config)] + [C.c_void_p] * 10
+        L.gso_pack_records.restype = None
+        L.gso_pack_records.argtypes = [C.POINTER(_Frame), C.c_void_p]
+        L.gso_forward_from_projected.restype = C.POINTER(_Frame)
+        L.gso_forward_from_projected.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Config)]
+        L.gso_backward_sums.restype = C.c_int
+        L.gso_backward_sums.argtypes = [C.POINTER(_Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gso_backward_points.restype = C.c_int
+        L.gso_backward_points.argtypes = [C.POINTER(_Frame)] + [C.c_void_p] * 6 + [C.c_int32, C.POINTER(Config)] + [C.c_void_p] * 5
         L.gso_frame_free.argtypes = [C.POINTER(_Frame)]
         L.gso_num_threads.restype = C.c_int
         for name, nargs in [("gso_inverse_se3_qt", None), ("gso_rotation_matrix_from_quaternion", None),
@@ -292,3 +300,73 @@ def backward(fwd, grad_rasterized_image, color_max_sh_band=2, cfg=None, want_buf
 
 def num_threads():
     return lib().gso_num_threads()
+
+
+# ---- the path cut at the projected records and the per-point sums (stand-ins for the library's staged entry points) ----
+def pack_records(fwd):
+    """(M,16) f32 records of a Forward: the per-point arrays of RAST:873-911, one row per in-camera point."""
+    out = np.zeros((fwd.M, 16), np.float32)
+    if fwd.M:
+        lib().gso_pack_records(fwd._handle, _p(out))
+    return out
+
+
+def forward_from_projected(records, H, W, cfg=None):
+    """Binning + sort + blend from records (any concatenation of shards' records).  Returns a Forward whose per-point
+    arrays are the records' and which has no point ids / mask (N = M)."""
+    cfg = cfg or default_config()
+    rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 16)
+    M = rec.shape[0]
+    h = lib().gso_forward_from_projected(M, _p(rec), int(H), int(W), C.byref(cfg))
+    if not h:
+        raise ValueError("gso_forward_from_projected rejected the arguments")
+    f = h.contents
+    K, T = f.K, f.T
+    A = {
+        "point_uv": _np_from(f.point_uv, (M, 2), np.float32),
+        "point_in_camera": _np_from(f.point_in_camera, (M, 3), np.float32),
+        "num_overlap_tiles": _np_from(f.num_overlap_tiles, (M,), np.int32),
+        "sort_key": _np_from(f.sort_key, (K,), np.int64),
+        "point_offset_with_sort_key": _np_from(f.point_offset_with_sort_key, (K,), np.int32),
+        "tile_points_start": _np_from(f.tile_points_start, (T,), np.int32),
+        "tile_points_end": _np_from(f.tile_points_end, (T,), np.int32),
+        "rasterized_image": _np_from(f.rasterized_image, (H, W, 3), np.float32),
+        "rasterized_depth": _np_from(f.rasterized_depth, (H, W), np.float32),
+        "pixel_accumulated_alpha": _np_from(f.pixel_accumulated_alpha, (H, W), np.float32),
+        "pixel_offset_of_last_effective_point": _np_from(f.pixel_offset_of_last_effective_point, (H, W), np.int32),
+        "pixel_valid_point_count": _np_from(f.pixel_valid_point_count, (H, W), np.int32),
+    }
+    return Forward(N=M, M=M, K=K, H=H, W=W, arrays=A, _handle=h, _inputs=None)
+
+
+def backward_sums(fwd, grad_rasterized_image):
+    """Loop 1 of the backward (RAST:531-705) for a rendered frame: (sums (M,12) f32, magnitude image (H,W,2))."""
+    g = _f32(grad_rasterized_image)
+    assert g.shape == (fwd.H, fwd.W, 3)
+    sums = np.zeros((max(fwd.M, 1), 12), np.float32)
+    mag_img = np.zeros((fwd.H, fwd.W, 2), np.float32)
+    if lib().gso_backward_sums(fwd._handle, _p(g), _p(sums), _p(mag_img)) != 0:
+        raise RuntimeError("gso_backward_sums failed")
+    return sums[:fwd.M], mag_img
+
+
+def backward_points(fwd, sums, color_max_sh_band=2, cfg=None):
+    """Loop 2 of the backward (RAST:708-772 + 1102-1125) for the shard `fwd` was computed from, given that shard's rows
+    of the sums.  Returns grad_pointcloud (N,3), grad_pointcloud_features (N,56) and the hook extras."""
+    cfg = cfg or default_config()
+    pc, feat, obj, q, t, Km = fwd._inputs
+    N, M = fwd.N, fwd.M
+    s = np.ascontiguousarray(sums, dtype=np.float32).reshape(-1, 12)
+    assert s.shape[0] == M
+    if M == 0:
+        s = np.zeros((1, 12), np.float32)
+    out = {"grad_pointcloud": np.zeros((N, 3), np.float32), "grad_pointcloud_features": np.zeros((N, 56), np.float32),
+           "grad_viewspace": np.zeros((N, 2), np.float32), "magnitude_grad_viewspace": np.zeros((N,), np.float32),
+           "num_affected_pixels": np.zeros((max(M, 1),), np.int32)}
+    rc = lib().gso_backward_points(fwd._handle, _p(pc), _p(feat), _p(obj), _p(t), _p(Km), _p(s), int(color_max_sh_band),
+                                   C.byref(cfg), _p(out["grad_pointcloud"]), _p(out["grad_pointcloud_features"]),
+                                   _p(out["grad_viewspace"]), _p(out["magnitude_grad_viewspace"]), _p(out["num_affected_pixels"]))
+    if rc != 0:
+        raise RuntimeError("gso_backward_points failed")
+    out["num_affected_pixels"] = out["num_affected_pixels"][:M]
+    return out

@@ -29,8 +29,9 @@ for k, v in acc.items():
     res[k]["issue_stall_over_wave_cycles"] = round(m.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
     idx = m.get("SQ_LDS_IDX_ACTIVE", 0.0)
     res[k]["lds_bank_conflict_fraction"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / idx, 4) if idx else None
-json.dump({"workload": wl, "note": "per-launch averages; ratios are per wave (quad-cycle units cancel)", "kernels": res},
-          open(dst, "w"), indent=1, sort_keys=True)
+doc = {"workload": wl, "note": "per-launch averages; ratios are per wave (quad-cycle units cancel)", "kernels": res}
+json.dump(doc, open(dst, "w"), indent=1, sort_keys=True)
+json.dump(doc, open(os.path.join(os.path.dirname(dst), "sq_counters.json"), "w"), indent=1, sort_keys=True)   # the copy bench.py reads
 for k in ("k_blend_bwd_tile", "k_blend_fwd", "k_sort_scatter", "k_bwd_points"):
     if k in res:
         print(k, {c: res[k][c] for c in res[k] if c.endswith("cycles") or c.endswith("fraction")})
