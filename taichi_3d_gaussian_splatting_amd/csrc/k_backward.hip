@@ -387,13 +387,34 @@ __global__ __launch_bounds__(256) void k_bwd_points(
         if (grad_uv) { grad_uv[2 * n] = 0.0f; grad_uv[2 * n + 1] = 0.0f; }
         if (mag) mag[n] = 0.0f;
     }
+    float s[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) s[k] = 0.0f;
     if (m >= 0) {
-        float s[PW];
-        {
-            const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
-            s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
-            s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
-        }
+        const float4 r0 = sums[3 * (size_t)m], r1 = sums[3 * (size_t)m + 1], r2 = sums[3 * (size_t)m + 2];
+        s[0] = r0.x; s[1] = r0.y; s[2] = r0.z; s[3] = r0.w; s[4] = r1.x; s[5] = r1.y; s[6] = r1.z; s[7] = r1.w;
+        s[8] = r2.x; s[9] = r2.y; s[10] = r2.z; s[11] = r2.w;
+    }
+    // An in-camera point no pixel took a contribution from (hidden behind saturated pixels, or below 1/255 everywhere:
+    // nine in ten at the headline config) has all-zero sums, hence all-zero gradients: its 224-byte feature row is not
+    // read and the Jacobian chain is not evaluated.  (The reference multiplies those zeros through the chain, which
+    // gives the same zeros unless a Jacobian entry is not finite.)
+    const bool touched = m >= 0 && __float_as_int(s[10]) != 0;
+    if (m >= 0 && !touched) {
+        grad_pc[3 * n] = 0.0f; grad_pc[3 * n + 1] = 0.0f; grad_pc[3 * n + 2] = 0.0f;
+        if (grad_uv) { grad_uv[2 * n] = 0.0f; grad_uv[2 * n + 1] = 0.0f; }
+        if (mag) mag[n] = 0.0f;
+        if (n_affected) n_affected[m] = 0;
+        if (hook_gpc) { hook_gpc[3 * (size_t)m] = 0.0f; hook_gpc[3 * (size_t)m + 1] = 0.0f; hook_gpc[3 * (size_t)m + 2] = 0.0f; }
+        if (hook_guv) { hook_guv[2 * (size_t)m] = 0.0f; hook_guv[2 * (size_t)m + 1] = 0.0f; }
+        if (hook_mag) hook_mag[m] = 0.0f;
+        if (hook_ids) hook_ids[m] = (int32_t)n;
+        if (hook_ntiles) hook_ntiles[m] = ntiles[m];
+        if (hook_depth) hook_depth[m] = GS_REC(PB, m).w;
+        if (hook_uv) { const float4 pa = GS_REC(PA, m); hook_uv[2 * (size_t)m] = pa.x; hook_uv[2 * (size_t)m + 1] = pa.y; }
+        if (c_num_in_camera) c_num_in_camera[n] += 1;                   // CTRL:133; the other five accumulators get += 0
+    }
+    if (touched) {
         {   // the per-splat factors k_blend_bwd_tile left out (see there): opacity, 0.5, (1 - opacity) * opacity
             const float apt = GS_REC(PB, m).z;
             s[0] *= apt; s[1] *= apt; s[9] *= apt;

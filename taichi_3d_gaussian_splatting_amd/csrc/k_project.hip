@@ -157,9 +157,13 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
 {
     __shared__ int wave_sum[4];
     __shared__ int wave_max[4];
+    // the four float4 of a record leave through LDS: a lane-per-record store writes 16 bytes out of every 64 per
+    // instruction; staged, each of the wave's four store instructions writes 1 KB of consecutive bytes
+    __shared__ float4 sOut[4][4 * 64];
     const int M = counters->M;
     int idx = blockIdx.x * 256 + threadIdx.x;
     int count = 0, depth_code = 0;
+    float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, recC = recA, recD = recA;
     if (idx < M) {
         int pid = ids[idx];
         float4* row4 = reinterpret_cast<float4*>(feat + (size_t)GS_NFEAT * pid);
@@ -172,8 +176,13 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         // RAST:196-205 normalise the rotation in place
         {
             float n = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2] + row[3] * row[3]);
-            row[0] = row[0] / n; row[1] = row[1] / n; row[2] = row[2] / n; row[3] = row[3] / n;
-            row4[0] = make_float4(row[0], row[1], row[2], row[3]);
+            const float q0 = row[0] / n, q1 = row[1] / n, q2 = row[2] / n, q3 = row[3] / n;
+            // written back only when the division changed a bit: a static scene (inference, a frozen parameter) is
+            // already normalised and costs no partial-line writes into the caller's rows
+            const bool changed = __float_as_int(q0) != __float_as_int(row[0]) || __float_as_int(q1) != __float_as_int(row[1]) ||
+                                 __float_as_int(q2) != __float_as_int(row[2]) || __float_as_int(q3) != __float_as_int(row[3]);
+            row[0] = q0; row[1] = q1; row[2] = q2; row[3] = q3;
+            if (changed) row4[0] = make_float4(q0, q1, q2, q3);
         }
         const GsPose& P = pose[obj[pid]];
         float Km[9];
@@ -264,14 +273,31 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         // whenever e < cut (margins are applied where it is used).  Not an index-determining value.
         float ra = rescale * alpha;
         float cut = ra > 0.0f ? __logf(GS_ALPHA_EPS / ra) : (ra == 0.0f ? 3.0e38f : -3.0e38f);
-        GS_REC(PA, idx) = make_float4(uv[0], uv[1], conic_a, conic_b);
-        GS_REC(PB, idx) = make_float4(conic_c, rescale, alpha, pcam[2]);
-        GS_REC(PC, idx) = make_float4(col[0], col[1], col[2], cut);
-        GS_REC(PD, idx) = make_float4(pcam[0], pcam[1], pcam[2], radii);
+        recA = make_float4(uv[0], uv[1], conic_a, conic_b);
+        recB = make_float4(conic_c, rescale, alpha, pcam[2]);
+        recC = make_float4(col[0], col[1], col[2], cut);
+        recD = make_float4(pcam[0], pcam[1], pcam[2], radii);
         boxes[idx] = make_ushort4((unsigned short)box[0], (unsigned short)box[1], (unsigned short)box[2], (unsigned short)box[3]);
         ntiles[idx] = count;
     }
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if GS_RS == 4
+    {
+        float4* mine = sOut[wave];
+        mine[lane] = recA; mine[64 + lane] = recB; mine[128 + lane] = recC; mine[192 + lane] = recD;
+        __builtin_amdgcn_wave_barrier();
+        const int wave_first = blockIdx.x * 256 + wave * 64;              // first record of this wave
+        const int n_rec = M - wave_first < 64 ? M - wave_first : 64;      // wave-uniform; <= 0 past the end
+        float4* dst = PA + (size_t)wave_first * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = k * 64 + lane;                                  // float4 e of the wave's 4 KB: record e / 4, quarter e % 4
+            if ((e >> 2) < n_rec) dst[e] = mine[(e & 3) * 64 + (e >> 2)];
+        }
+    }
+#else
+    if (idx < M) { GS_REC(PA, idx) = recA; GS_REC(PB, idx) = recB; GS_REC(PC, idx) = recC; GS_REC(PD, idx) = recD; }
+#endif
     int s = gs_wave_sum_i(count);
     int mx = gs_wave_max_i(depth_code);
     if (lane == 0) { wave_sum[wave] = s; wave_max[wave] = mx; }
