@@ -35,9 +35,10 @@
 // written and their `visited` byte stays 0 (the array is cleared by the k_tile_order launch of each backward).
 // Tiles in order of decreasing backward work (entries to walk), so that the heaviest tiles are
 // dispatched first and the launch does not end on a few long-running waves.  Counting sort in one
-// workgroup: 2048 bins of width 1 (work >= 2047 shares the first bin).  Pure scheduling: results do
-// not depend on it.
+// workgroup: 2048 bins of width ORDER_BIN_WIDTH (more work shares the first bin).  Pure scheduling: results do
+// not depend on it.  Work = the (splat, quadrant) evaluations the forward counted for the tile.
 #define ORDER_BINS 2048
+#define ORDER_BIN_WIDTH 4
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order,
                                                      uint4* __restrict__ clear, size_t clear_vec)
 {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
     __syncthreads();
     for (int i = t; i < T; i += 1024) {
-        int w = tile_work[i]; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+        int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
         atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);               // bin 0 = heaviest
     }
     __syncthreads();
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     bins[2 * t] = excl; bins[2 * t + 1] = excl + a;
     __syncthreads();
     for (int i = t; i < T; i += 1024) {
-        int w = tile_work[i]; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+        int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
         const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
         order[pos] = i;
     }

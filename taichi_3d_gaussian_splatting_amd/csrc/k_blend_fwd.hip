@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
 
     float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, acc_d = 0.0f, norm = 0.0f;
     int last = start, count = 0;
+    int evals = 0;                 // splats that survived the cull in this quadrant (wave-uniform): what the backward will evaluate again
     // a pixel of a partial edge tile that lies outside the image does not exist (extension; W,H % 16 == 0 in the reference)
     const bool inside = pixel_u < W && pixel_v < H;
     // Lane predicates live as wave-uniform 64-bit masks in SGPRs (votes fold into the v_cmp that made them, and
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         unsigned long long mask = gs_ballot(keep);
         GS_STAT(0, 1); GS_STAT(1, __popcll(mask));
         if (mask == 0ull) continue;
+        evals += __popcll(mask);
         sRec[wave][lane][0] = A; sRec[wave][lane][1] = B; sRec[wave][lane][2] = C;
         __builtin_amdgcn_wave_barrier();
         while (mask) {
@@ -98,9 +100,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
         acc_alpha[o] = 1.0f - T_i;
         last_out[o] = last;
         count_out[o] = count;
-        // entries the backward will have to walk in this tile (largest last-effective index): scheduling hint only
-        const int wmax = gs_wave_max_i(last - start);
-        if (lane == 0 && wmax > 0) atomicMax(&tile_work[tile], wmax);
+        // (splat, quadrant) evaluations of this tile: the backward repeats them (same cull, same stop), so their number
+        // predicts its cost per tile far better than the list length does.  Scheduling hint only.
+        if (lane == 0 && evals > 0) atomicAdd(&tile_work[tile], evals);
     }
 }
 
