@@ -128,7 +128,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" const char* gs_kernel_names(void)
 {
-    return "k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,k_sort_row_totals,"
+    return "k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,"
            "k_sort_rowscan,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
 }
 
@@ -659,7 +659,8 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     const size_t flag_bytes = (rows + 15) / 16 * 16;
     hipError_t e = c->partial.ensure(rows * 12 * sizeof(float), &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: partial-sum buffer");
-    e = c->visited.ensure(flag_bytes + 64, &c->device_bytes);
+    const size_t Mp = (size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1);
+    e = c->visited.ensure(flag_bytes + 64 + Mp + 16, &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: visited buffer");
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
@@ -675,7 +676,8 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
     a.G = G;
-    a.visited_bytes = flag_bytes + 48;
+    a.visited_bytes = flag_bytes + 64 + Mp;
+    a.touched = c->visited.as<uint8_t>() + flag_bytes + 64;
     a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + flag_bytes);
     a.sums = sums_out;
     a.mag_image = mag_image;

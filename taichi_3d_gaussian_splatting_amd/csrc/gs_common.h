@@ -168,7 +168,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 // ---- optional per-kernel timing with HIP events on the launch stream -------------
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
 enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
-                  KID_SORT_HIST, KID_SORT_TOTALS, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
+                  KID_SORT_HIST, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
                   KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
@@ -234,7 +234,8 @@ struct GsBackwardArgs {
     int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
     uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward
-    size_t visited_bytes;           // K rounded up to 16 + 48: flags, then one all-zero 48-byte row
+    size_t visited_bytes;           // flags (K*G rounded up to 16), one all-zero 48-byte row, 16 bytes of padding, then `touched`: all cleared per backward
+    uint8_t* touched;               // (M) 1 where some pixel took a contribution from the point
     const float4* zero_row;         // that row
     float4* sums;                   // (M,3) per-point sums of the visited rows (count as int32 bits in [10])
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                                                        const uint32_t* __restrict__ offsets,
                                                        const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
                                                        const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
-                                                       float* __restrict__ partial, uint8_t* __restrict__ visited, float* __restrict__ mag_image)
+                                                       float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
+                                                       float* __restrict__ mag_image)
 {
     __shared__ float4 sRec[64][3];             // the batch's splat records
     __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
                     float* row = partial + (size_t)sj * PW;
                     if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
-                    if (lane == 63) visited[sj] = 1;
+                    if (lane == 63) { visited[sj] = 1; touched[__builtin_amdgcn_readlane(p, j)] = 1; }   // row written; point has a contribution
                     __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -279,15 +280,18 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 // (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the critical path.
 #define SUM_ROWS_SMALL 32
 __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
-                                                  const float* __restrict__ partial, const uint8_t* __restrict__ visited,
+                                                  const float* __restrict__ partial, const uint8_t* __restrict__ visited, const uint8_t* __restrict__ touched,
                                                   const float4* __restrict__ zero_row, float4* __restrict__ sums)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = t >> 2, q = t & 3;
     const int lane = threadIdx.x & 63;
     const bool valid = m < M;
-    const uint32_t off = valid ? offsets[m] * (uint32_t)G : 0u;      // G rows per (point, tile) pair
-    const int cnt = valid ? ntiles[m] * G : 0;
+    // a point no pixel took a contribution from (nine in ten at the headline config) has no visited row: its byte of
+    // `touched` says so and none of its flags or rows is looked at
+    const bool live = valid && touched[m] != 0;
+    const uint32_t off = live ? offsets[m] * (uint32_t)G : 0u;       // G rows per (point, tile) pair
+    const int cnt = live ? ntiles[m] * G : 0;
     float v[11];
     int npix = 0;                                                     // column 10 is an integer count: summed as one
 #pragma unroll
@@ -635,18 +639,18 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
                                                                                          reinterpret_cast<uint4*>(a.visited), clear_vec));
         if (a.G == 1)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
         else if (a.G == 2)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
         else
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.mag_image));
+                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
     if (a.M > 0 && a.T > 0 && a.K > 0)
-        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited,
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited, a.touched,
                                                                                   a.zero_row, a.sums));
     else if (a.M > 0)
         (void)hipMemsetAsync(a.sums, 0, sizeof(float) * PW * (size_t)a.M, s);          // no pairs at all: every sum is zero

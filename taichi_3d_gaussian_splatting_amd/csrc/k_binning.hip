@@ -122,37 +122,16 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys
     hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
 }
 
-// The [digit][block] table of per-block counts becomes global offsets in two small launches:
-// k_sort_row_totals sums each digit's row; k_sort_rowscan (one block per digit) adds the totals of all
-// smaller digits to an exclusive scan along the digit's own row.  No atomics, fixed order.
-__global__ __launch_bounds__(256) void k_sort_row_totals(const uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
-{
-    __shared__ uint32_t wsum[4];
-    const int d = blockIdx.x, t = threadIdx.x;
-    const uint32_t* row = hist + (size_t)d * nblocks;
-    uint32_t v = 0;
-    for (int i = t; i < nblocks; i += 256) v += row[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((t & 63) == 0) wsum[t >> 6] = v;
-    __syncthreads();
-    if (t == 0) totals[d] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ __launch_bounds__(1024) void k_sort_rowscan(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+// The [digit][block] table of per-block counts becomes global offsets in ONE small launch plus a few instructions of
+// the scatter's prologue: k_sort_rowscan (one block per digit) scans the digit's own row exclusively and leaves the
+// row's total in `totals`; every scatter block then adds, for each digit, the totals of all smaller digits (a
+// 256-element block scan).  No atomics, no cross-block waiting, fixed order.
+__global__ __launch_bounds__(1024) void k_sort_rowscan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
                                                        uint32_t* __restrict__ offsets_out, int nblocks)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t base_s;
     const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t v = (t < d) ? totals[t] : 0u;                      // d <= 255 < 1024 threads
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) wsum[wave] = v;
-    __syncthreads();
-    if (t == 0) { uint32_t b = 0; for (int w = 0; w < 16; ++w) b += wsum[w]; base_s = b; }
-    __syncthreads();
-    uint32_t carry = base_s;
+    uint32_t carry = 0;
     const uint32_t* row = hist + (size_t)d * nblocks;
     uint32_t* orow = offsets_out + (size_t)d * nblocks;
     for (int start = 0; start < nblocks; start += 1024) {
@@ -171,6 +150,7 @@ __global__ __launch_bounds__(1024) void k_sort_rowscan(const uint32_t* __restric
         for (int w = 0; w < 16; ++w) tot += wsum[w];
         carry += tot;
     }
+    if (t == 0) totals[d] = carry;
 }
 
 // Stable scatter of one radix pass.  Per 4096-key tile: (1) every wave ranks its 1024 keys with
@@ -183,7 +163,7 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out,
                                                       uint32_t n, int shift, const uint32_t* __restrict__ hist_scanned,
-                                                      int nblocks, int tiles_per_block)
+                                                      const uint32_t* __restrict__ totals, int nblocks, int tiles_per_block)
 {
     __shared__ uint32_t cnt[4][256];      // per-wave digit counts, then per-wave start inside the tile
     __shared__ uint32_t gbase[256];       // running global offset of each digit for this block
@@ -193,7 +173,18 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
     __shared__ int32_t svals[SORT_TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    gbase[t] = hist_scanned[t * nblocks + blockIdx.x];
+    {   // global start of digit t = totals of all smaller digits (exclusive scan of the 256 row totals) + this block's offset in the row
+        const uint32_t tot = totals[t];
+        uint32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wtot[w];
+        gbase[t] = (woff + incl - tot) + hist_scanned[t * nblocks + blockIdx.x];
+        __syncthreads();
+    }
     // one 4096-pair tile; FULL (every tile but the last of the array) drops all bounds predicates
     auto do_tile = [&](auto full_tag, const uint64_t tile_base, const uint32_t tile_n) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -313,7 +304,7 @@ size_t gs_sort_hist_elems(uint32_t K)
     return (size_t)2 * 256 * nb;      // raw counts + scanned offsets
 }
 
-size_t gs_scan_tmp_elems(size_t) { return 256; }      // the 256 digit totals of k_sort_row_totals
+size_t gs_scan_tmp_elems(size_t) { return 256; }      // the 256 row totals of k_sort_rowscan
 
 template <typename KeyT>
 static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
@@ -333,9 +324,8 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     for (int shift = 0; shift < a.key_bits; shift += 8) {
         uint32_t* offs = a.hist + (size_t)256 * nb;                 // second half of the table: scanned offsets
         GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
-        GS_TIMED(a.prof, KID_SORT_TOTALS, s, k_sort_row_totals<<<256, 256, 0, s>>>(a.hist, a.scan_tmp, nb));
         GS_TIMED(a.prof, KID_SORT_ROWSCAN, s, k_sort_rowscan<<<256, 1024, 0, s>>>(a.hist, a.scan_tmp, offs, nb));
-        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, offs, nb, tpb));
+        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, offs, a.scan_tmp, nb, tpb));
         KeyT* tk = kin; kin = kout; kout = tk;
         int32_t* tv = vin; vin = vout; vout = tv;
     }
