@@ -129,7 +129,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* gs_kernel_names(void)
 {
     return "k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,"
-           "k_sort_rowscan,k_sort_scatter,k_tile_ranges,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
+           "k_sort_rowscan,k_sort_scatter,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
 }
 
 extern "C" int gs_create(int32_t device, gs_ctx** out)
@@ -434,6 +434,7 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     fa.prof = &c->prof;
     fa.H = H; fa.W = W; fa.tiles_x = tiles_x; fa.T = T; fa.rgb_only = cfg->rgb_only;
     fa.tile_start = ba.tile_start; fa.tile_end = ba.tile_end; fa.vals_sorted = f->vals_sorted;
+    fa.keys_sorted = f->keys_sorted; fa.key64 = key64; fa.depth_bits = depth_bits; fa.K = K;
     fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
     fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;

@@ -168,7 +168,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 // ---- optional per-kernel timing with HIP events on the launch stream -------------
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
 enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
-                  KID_SORT_HIST, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_TILE_RANGES, KID_BLEND_FWD,
+                  KID_SORT_HIST, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_BLEND_FWD,
                   KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
@@ -216,7 +216,9 @@ size_t gs_scan_tmp_elems(size_t n);
 struct GsBlendFwdArgs {
     GsProf* prof;
     int H, W, tiles_x, T; int rgb_only;
-    const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
+    int32_t *tile_start, *tile_end;      // written by the blend kernel itself (each tile's block finds its range in the sorted keys)
+    const void* keys_sorted; int key64, depth_bits; uint32_t K;
+    const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
     int32_t* tile_work;            // (T) zeroed together with the tile ranges; max over the tile's pixels of last - start

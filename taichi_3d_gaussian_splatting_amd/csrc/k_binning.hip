@@ -3,7 +3,7 @@
 //                   exclusive scan of RAST:913-922 folded in (block-local scan + block offset)
 //   k_sort_hist / k_sort_scatter   Tensor.sort() + gather, RAST:947-949 (stable: ties keep
 //                   ascending in-camera offset)
-//   k_tile_ranges   find_tile_start_and_end, RAST:175-193
+//   (find_tile_start_and_end, RAST:175-193: a 64-ary search in k_blend_fwd's prologue, no kernel here)
 //
 // Keys are stored compactly: (tile_id << depth_bits) | depth_code, depth_bits = bits of the
 // largest depth code in THIS frame, so only the significant bits are radix-sorted.  The order
@@ -271,21 +271,6 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ k
     }
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_tile_ranges(const KeyT* __restrict__ keys, uint32_t n, int depth_bits,
-                                                     int32_t* __restrict__ tile_start, int32_t* __restrict__ tile_end)
-{
-    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= n) return;
-    int32_t tile = (int32_t)(keys[idx] >> depth_bits);
-    if (idx + 1 < n) {
-        int32_t next = (int32_t)(keys[idx + 1] >> depth_bits);
-        if (tile != next) { tile_start[next] = (int32_t)(idx + 1); tile_end[tile] = (int32_t)(idx + 1); }
-    } else {
-        tile_end[tile] = (int32_t)n;
-    }
-}
-
 static void sort_geometry(uint32_t K, int* nblocks, int* tiles_per_block)
 {
     uint32_t tiles = (K + SORT_TILE - 1) / SORT_TILE;
@@ -331,7 +316,7 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     }
     *a.keys_sorted = kin;
     *a.vals_sorted = vin;
-    GS_TIMED(a.prof, KID_TILE_RANGES, s, k_tile_ranges<KeyT><<<(a.K + 255) / 256, 256, 0, s>>>(kin, a.K, a.depth_bits, a.tile_start, a.tile_end));
+    // (find_tile_start_and_end, RAST:175-193, has no launch of its own: k_blend_fwd's blocks look their range up in these keys)
 }
 
 void gs_launch_binning(const GsBinArgs& a, hipStream_t s)

@@ -15,8 +15,30 @@
 #include "gs_common.h"
 #include "gs_cull.h"
 
+// find_tile_start_and_end (RAST:175-193) without a launch of its own: the first index of the sorted, compact keys
+// (tile << depth_bits | depth code) whose tile is >= `tile`, by a 64-ary search -- every step the wave's 64 lanes probe
+// 64 positions of the remaining span and a ballot narrows it 64-fold (four or five dependent loads for millions of keys).
+template <typename KeyT>
+__device__ __forceinline__ int gs_first_key_of_tile(const KeyT* __restrict__ keys, uint32_t K, int depth_bits, uint32_t tile, int lane)
+{
+    uint32_t lo = 0, hi = K;                       // answer in [lo, hi]; every index < lo is below the tile, index hi (if < K) is not
+    while (lo < hi) {
+        const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint32_t mine = (uint32_t)(lane + 1) * step;
+        const uint32_t p = lo + (mine < span ? mine : span) - 1u;
+        const unsigned long long b = gs_ballot((uint32_t)(keys[p] >> depth_bits) >= tile);
+        if (b == 0ull) { lo = hi; break; }
+        const uint32_t f = (uint32_t)__builtin_ctzll(b);
+        const uint32_t pf = lo + ((f + 1u) * step < span ? (f + 1u) * step : span) - 1u;
+        if (f > 0u) lo = lo + (f * step < span ? f * step : span);      // = p_(f-1) + 1
+        hi = pf;
+    }
+    return (int)lo;
+}
+
 template <bool RGB_ONLY>
-__global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+__global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_start, int32_t* __restrict__ tile_end,
+                                                   const void* __restrict__ sorted_keys, int key64, int depth_bits, uint32_t K,
                                                    const int32_t* __restrict__ sorted_vals,
                                                    const float4* __restrict__ PA, const float4* __restrict__ PB,
                                                    const float4* __restrict__ PC, int W, int H, int tiles_x,
@@ -32,7 +54,19 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const int32_t* __restrict__ t
     const int pixel_u = qx + (lane & 7), pixel_v = qy + (lane >> 3);
     const float px = (float)pixel_u + 0.5f, py = (float)pixel_v + 0.5f;
     const float rx0 = (float)qx + 0.5f, ry0 = (float)qy + 0.5f;
-    const int start = tile_start[tile], end = tile_end[tile];
+    // the tile's range in the sorted list: wave 0 finds where the tile starts, wave 1 where the next one does; an empty
+    // tile keeps the reference's zero-initialised 0, 0 (RAST:954-957).  The ranges are stored for the backward.
+    __shared__ int sRange[2];
+    if (wave < 2) {
+        const uint32_t want = (uint32_t)tile + (uint32_t)wave;
+        const int r = K == 0u ? 0 : (key64 ? gs_first_key_of_tile(reinterpret_cast<const uint64_t*>(sorted_keys), K, depth_bits, want, lane)
+                                           : gs_first_key_of_tile(reinterpret_cast<const uint32_t*>(sorted_keys), K, depth_bits, want, lane));
+        if (lane == 0) sRange[wave] = r;
+    }
+    __syncthreads();
+    const bool occupied = sRange[1] > sRange[0];
+    const int start = occupied ? sRange[0] : 0, end = occupied ? sRange[1] : 0;
+    if (threadIdx.x == 0) { tile_start[tile] = start; tile_end[tile] = end; }
 #ifdef GS_STATS
     const unsigned long long gs_t0 = wall_clock64();
 #endif
@@ -110,9 +144,9 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
     if (a.rgb_only)
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
     else
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
                                                                               a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
 }
