@@ -128,7 +128,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" const char* gs_kernel_names(void)
 {
-    return "k_filter,k_scan_tiles_publish,k_compact,k_project,k_keygen,k_sort_hist,"
+    return "k_filter,k_scan_tiles_publish,k_project,k_keygen,k_sort_hist,"
            "k_sort_rowscan,k_sort_scatter,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
 }
 
@@ -421,6 +421,7 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     ba.N = n_rows; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
+    ba.block_offsets = pa.block_offsets; ba.block_counts = pa.block_counts;     // NULL for records that did not come from k_project
     ba.offsets = B.offsets.as<uint32_t>();
     ba.keys_a = B.keys_a.p; ba.keys_b = B.keys_b.p; ba.key64 = key64;
     ba.vals_a = B.vals_a.as<int32_t>(); ba.vals_b = B.vals_b.as<int32_t>();

@@ -167,7 +167,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 
 // ---- optional per-kernel timing with HIP events on the launch stream -------------
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
-enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_COMPACT, KID_PROJECT, KID_KEYGEN,
+enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_PROJECT, KID_KEYGEN,
                   KID_SORT_HIST, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_BLEND_FWD,
                   KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
 struct GsProf;
@@ -201,6 +201,7 @@ struct GsBinArgs {
     GsProf* prof;
     int64_t N; int M; uint32_t K; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
     const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
+    const int32_t *block_offsets, *block_counts;   // k_project's blocks (first in-camera offset, count); NULL: 256 consecutive records per block
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
     void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64
     int key64;                                             // depth bits + tile bits > 32

@@ -19,7 +19,9 @@
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, const ushort4* __restrict__ boxes,
                                                 const int32_t* __restrict__ ntiles,
-                                                const uint32_t* __restrict__ tile_block_offsets, int M, int tiles_x,
+                                                const uint32_t* __restrict__ tile_block_offsets,
+                                                const int32_t* __restrict__ block_offsets, const int32_t* __restrict__ block_counts,
+                                                int M, int tiles_x,
                                                 float depth_scale, int depth_bits, uint32_t K_cap,
                                                 uint32_t* __restrict__ offsets, KeyT* __restrict__ keys,
                                                 int32_t* __restrict__ vals)
@@ -28,7 +30,11 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
     __shared__ KeyT sk[4][64 * KEYGEN_SMALL];        // pairs of the wave's small points: key, slot, point
     __shared__ uint32_t ss[4][64 * KEYGEN_SMALL];
     __shared__ int32_t sv[4][64 * KEYGEN_SMALL];
-    int idx = blockIdx.x * 256 + threadIdx.x;
+    // same blocks as the kernel that produced ntiles / tile_block_offsets: k_project's (256 rows of the point cloud each, in-camera
+    // points dense from block_offsets[b]) or, for records that arrived from elsewhere, 256 consecutive records
+    const int first = block_offsets ? block_offsets[blockIdx.x] : (int)blockIdx.x * 256;
+    const int mine = block_offsets ? block_counts[blockIdx.x] : min(256, M - first);
+    const int idx = (int)threadIdx.x < mine ? first + (int)threadIdx.x : M;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t n = idx < M ? (uint32_t)ntiles[idx] : 0u;
     uint32_t incl = n;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
         const int bu0 = __builtin_amdgcn_readlane((int)bx.x, j), bv0 = __builtin_amdgcn_readlane((int)bx.z, j);
         const int bdv = __builtin_amdgcn_readlane(dv, j);
         const uint32_t bcode = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)depth_code, j);
-        const int bidx = (int)(blockIdx.x * 256 + (threadIdx.x & ~63)) + j;
+        const int bidx = first + (int)(threadIdx.x & ~63) + j;
         for (int t = lane; t < bn; t += 64) {
             const int tu = bu0 + t / bdv, tv = bv0 + t % bdv;                       // slot order: tile_u outer, tile_v inner
             const uint32_t slot = boff + (uint32_t)t;
@@ -299,8 +305,9 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     *a.keys_sorted = a.keys_a;
     *a.vals_sorted = a.vals_a;
     if (a.N == 0 || a.M == 0) return;
-    GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<(a.M + 255) / 256, 256, 0, s>>>(
-        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
+    const unsigned kg_blocks = a.block_offsets ? (unsigned)((a.N + 255) / 256) : (unsigned)((a.M + 255) / 256);
+    GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<kg_blocks, 256, 0, s>>>(
+        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.block_offsets, a.block_counts, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
     if (a.K == 0) return;
     int nb, tpb;
     sort_geometry(a.K, &nb, &tpb);

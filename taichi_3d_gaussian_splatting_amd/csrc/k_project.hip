@@ -2,9 +2,8 @@
 //   k_filter         filter_point_in_camera, RAST:31-78, with the host prologue RAST:841-846 (inverse_SE3_qt_torch,
 //                    UTIL:426-432) folded in: every block derives the pose records itself
 //   k_scan_tiles_publish   exclusive scan of the per-block tile counts (replaces the torch cumsum glue) + hand-over of M, K
-//   k_compact        point_id[mask], RAST:861-870 (ascending ids)
-//   k_project        generate_point_attributes_in_camera_plane RAST:239-315 fused with
-//                    generate_num_overlap_tiles RAST:106-128
+//   k_project        point_id[mask] (RAST:861-870, ascending ids) + generate_point_attributes_in_camera_plane RAST:239-315
+//                    + generate_num_overlap_tiles RAST:106-128 in one kernel
 // All HBM-bound streaming kernels; layouts in DESIGN.md.
 #include "gs_common.h"
 
@@ -116,39 +115,17 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-// Every block sums the counts of the blocks before it (a few thousand L2-resident ints) instead of waiting for a
-// separate scan launch; the last block also publishes M.
-__global__ __launch_bounds__(256) void k_compact(const int8_t* __restrict__ mask, const int32_t* __restrict__ block_counts,
-                                                 int64_t N, int32_t* __restrict__ ids, int32_t* __restrict__ cam_index,
-                                                 GsCounters* __restrict__ counters)
-{
-    __shared__ int wave_cnt[4];
-    __shared__ int wave_pre[4];
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool in = i < N && mask[i] != 0;
-    unsigned long long b = gs_ballot(in);
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int pre = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) pre += block_counts[j];
-    pre = gs_wave_sum_i(pre);
-    if (lane == 0) { wave_cnt[wave] = __popcll(b); wave_pre[wave] = pre; }
-    __syncthreads();
-    const int block_offset = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3];
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
-    int rank = __popcll(b & ((1ull << lane) - 1ull));
-    int m = block_offset + woff + rank;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        counters->M = block_offset + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    if (in) ids[m] = (int32_t)i;
-    if (i < N) cam_index[i] = in ? m : -1;
-}
-
 // ---------------------------------------------------------------------------------
-// One thread per in-camera point (dense over M).
+// Compaction (point_id[mask], RAST:861-870, ascending ids) fused with the projection: a block takes 256 consecutive
+// rows of the point cloud, sums the in-camera counts of the blocks before it (a few thousand L2-resident ints, instead
+// of waiting for a scan launch), compacts its own in-camera rows through LDS and then projects them with its first
+// `cnt` threads -- dense within the block, and the records of block b start at in-camera offset block_offsets[b].
 __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, float* __restrict__ feat,
                                                  const int32_t* __restrict__ obj, const float* __restrict__ Kmat,
-                                                 const GsPose* __restrict__ pose, const int32_t* __restrict__ ids,
+                                                 const GsPose* __restrict__ pose, const int8_t* __restrict__ mask,
+                                                 const int32_t* __restrict__ block_counts, int64_t N,
+                                                 int32_t* __restrict__ ids, int32_t* __restrict__ cam_index,
+                                                 int32_t* __restrict__ block_offsets,
                                                  int W, int H, float depth_scale,
                                                  float4* __restrict__ PA, float4* __restrict__ PB, float4* __restrict__ PC,
                                                  float4* __restrict__ PD, ushort4* __restrict__ boxes,
@@ -160,12 +137,38 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
     // the four float4 of a record leave through LDS: a lane-per-record store writes 16 bytes out of every 64 per
     // instruction; staged, each of the wave's four store instructions writes 1 KB of consecutive bytes
     __shared__ float4 sOut[4][4 * 64];
-    const int M = counters->M;
-    int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int sIds[256];
+    __shared__ int wave_cnt[4];
+    __shared__ int wave_pre[4];
+    int block_offset, cnt;
+    {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const bool in = i < N && mask[i] != 0;
+        const unsigned long long b = gs_ballot(in);
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        int pre = 0;
+        for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) pre += block_counts[j];
+        pre = gs_wave_sum_i(pre);
+        if (lane_ == 0) { wave_cnt[wave_] = __popcll(b); wave_pre[wave_] = pre; }
+        __syncthreads();
+        block_offset = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3];
+        cnt = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        int woff = 0;
+        for (int w = 0; w < wave_; ++w) woff += wave_cnt[w];
+        const int r = woff + __popcll(b & ((1ull << lane_) - 1ull));
+        if (in) { sIds[r] = (int)i; ids[block_offset + r] = (int32_t)i; }
+        if (i < N) cam_index[i] = in ? block_offset + r : -1;
+        if (threadIdx.x == 0) {
+            block_offsets[blockIdx.x] = block_offset;
+            if (blockIdx.x == gridDim.x - 1) counters->M = block_offset + cnt;
+        }
+        __syncthreads();
+    }
+    const int idx = block_offset + threadIdx.x;                      // in-camera offset of this thread's point
     int count = 0, depth_code = 0;
     float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, recC = recA, recD = recA;
-    if (idx < M) {
-        int pid = ids[idx];
+    if ((int)threadIdx.x < cnt) {
+        int pid = sIds[threadIdx.x];
         float4* row4 = reinterpret_cast<float4*>(feat + (size_t)GS_NFEAT * pid);
         float row[GS_NFEAT];
 #pragma unroll
@@ -286,8 +289,8 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         float4* mine = sOut[wave];
         mine[lane] = recA; mine[64 + lane] = recB; mine[128 + lane] = recC; mine[192 + lane] = recD;
         __builtin_amdgcn_wave_barrier();
-        const int wave_first = blockIdx.x * 256 + wave * 64;              // first record of this wave
-        const int n_rec = M - wave_first < 64 ? M - wave_first : 64;      // wave-uniform; <= 0 past the end
+        const int wave_first = block_offset + wave * 64;                  // first record of this wave
+        const int n_rec = cnt - wave * 64 < 64 ? cnt - wave * 64 : 64;    // wave-uniform; <= 0 past the block's last in-camera point
         float4* dst = PA + (size_t)wave_first * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         }
     }
 #else
-    if (idx < M) { GS_REC(PA, idx) = recA; GS_REC(PB, idx) = recB; GS_REC(PC, idx) = recC; GS_REC(PD, idx) = recD; }
+    if ((int)threadIdx.x < cnt) { GS_REC(PA, idx) = recA; GS_REC(PB, idx) = recB; GS_REC(PC, idx) = recC; GS_REC(PD, idx) = recD; }
 #endif
     int s = gs_wave_sum_i(count);
     int mx = gs_wave_max_i(depth_code);
@@ -402,8 +405,8 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.q_pc, a.t_pc, a.n_objects,
                                                             a.pose, a.counters, a.N, a.W, a.H, a.near_plane, a.far_plane, a.mask,
                                                             a.block_counts));
-    GS_TIMED(a.prof, KID_COMPACT, s, k_compact<<<nb, 256, 0, s>>>(a.mask, a.block_counts, a.N, a.ids, a.cam_index, a.counters));
-    GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.ids, a.W, a.H,
+    GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.mask, a.block_counts, a.N,
+                                                              a.ids, a.cam_index, a.block_offsets, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters));
     GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
