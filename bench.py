@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--scheme", choices=["view", "gaussian"], default="view",
                     help="N > 1: 'view' = parameters replicated, gradient all-reduce; 'gaussian' = every rank owns 1/N of the Gaussians "
                          "and renders one view, projected records and per-splat sums exchanged by two all-to-alls, no all-reduce")
+    ap.add_argument("--rgb-only", action="store_true",
+                    help="forward mode only: GaussianPointCloudRasterisationConfig.rgb_only=True (RAST:781, 478-484): only the image is produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--breakdown-steps", type=int, default=10)
@@ -120,8 +122,12 @@ def main():
         q_pointcloud_camera=torch.tensor(q, device=dev), t_pointcloud_camera=torch.tensor(t, device=dev),
         color_max_sh_band=3)
     hook_calls = []
-    rcfg = Rast.GaussianPointCloudRasterisationConfig()
+    if args.rgb_only and mode != "forward":
+        raise SystemExit("--rgb-only frames cannot be back-propagated (RAST:478-484): use --mode forward")
+    rcfg = Rast.GaussianPointCloudRasterisationConfig(rgb_only=bool(args.rgb_only))
     rcfg.allow_partial_tiles = partial_tiles
+    probe_cfg = Rast.GaussianPointCloudRasterisationConfig()
+    probe_cfg.allow_partial_tiles = partial_tiles
     module = Rast(rcfg,
                   backward_valid_point_hook=(lambda payload: hook_calls.append(1)) if args.hook else None)
     L = _native.lib()
@@ -203,7 +209,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     sync_all()
-    probe = Rast(rcfg)                           # an inference call leaves a frame that can still be inspected
+    probe = Rast(probe_cfg)                      # an inference call (all outputs) leaves a frame that can still be inspected
     inp.q_pointcloud_camera, inp.t_pointcloud_camera = poses[my_views[0]]
     with torch.no_grad():
         probe(inp)
@@ -296,7 +302,7 @@ def main():
                        "exchange_bytes_sent_per_rank_per_step": (gp_stats.get("bytes_sent") if args.scheme == "gaussian"
                                                                  else (0 if world == 1 else 236 * N * (V if args.reduce == "view" else 1))),
                        "rehearsal": rehearsal,
-                       "backward_hook": bool(args.hook)},
+                       "backward_hook": bool(args.hook), "rgb_only": bool(args.rgb_only)},
             "roofline": {"kernel": dominant, "bound": bound,
                          "bound_detail": ("FP32 vector ALU (no MFMA anywhere on this path: there is no dense contraction); the schema's "
                                           "'mfma' slot is used because 157.3 TFLOP/s is both the f32 vector and the f32 MFMA dense peak; "

@@ -153,8 +153,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         class _module_function(torch.autograd.Function):
             @staticmethod
             def forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
-                        q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
-                needs_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])   # False under torch.no_grad()
+                        q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, grad_mode):
+                # ctx.needs_input_grad says whether the inputs require grad, not whether a graph is being recorded (it is True
+                # under torch.no_grad() too, and grad mode is always off inside forward): the caller passes the grad mode in
+                needs_grad = bool(grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
                 outs, frame = module._run_forward(pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
                                                   q_pointcloud_camera, t_pointcloud_camera, camera_info, keep=needs_grad)
                 image, depth, acc_alpha, last, count = outs
@@ -187,7 +189,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # the frame is NOT released here: like the reference's saved tensors it lives as long as the graph
                     # node does, so backward(retain_graph=True) followed by another backward works; it goes back to the
                     # pool when autograd drops the node (_Frame.__del__)
-                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
+                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None, None
 
         self._module_function = _module_function
 
@@ -323,4 +325,4 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         return self._module_function.apply(
             input_data.point_cloud, input_data.point_cloud_features, input_data.point_invalid_mask,
             input_data.point_object_id, input_data.q_pointcloud_camera, input_data.t_pointcloud_camera,
-            camera_info, input_data.color_max_sh_band)
+            camera_info, input_data.color_max_sh_band, torch.is_grad_enabled())

@@ -118,11 +118,15 @@ def test_rgb_only_and_no_grad(P):
     f, _ = P.run_oracle(s, q, t)
     for rgb_only in (False, True):
         module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig(rgb_only=rgb_only))
-        with torch.no_grad():
-            image, depth, count = module(P.make_input(s, q, t, requires_grad=False))
-        assert P.rel_err(image.cpu().numpy(), f.rasterized_image) < P.IMAGE_TOL
-        if not rgb_only:
-            assert np.array_equal(count.cpu().numpy(), f.pixel_valid_point_count)
+        for requires_grad in (False, True):      # parameters that require grad, rendered under no_grad (a trainer's validation pass)
+            with torch.no_grad():
+                image, depth, count = module(P.make_input(s, q, t, requires_grad=requires_grad))
+            assert P.rel_err(image.cpu().numpy(), f.rasterized_image) < P.IMAGE_TOL
+            if not rgb_only:
+                assert np.array_equal(count.cpu().numpy(), f.pixel_valid_point_count)
+        if rgb_only:                                  # with a graph being recorded there is nothing to back-propagate through (RAST:478-484)
+            with pytest.raises(RuntimeError, match="rgb_only"):
+                module(P.make_input(s, q, t, requires_grad=True))
 
 
 def test_backward_is_bitwise_reproducible(P):
