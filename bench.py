@@ -65,9 +65,11 @@ def main():
                          "BackwardValidPointHookInput payload; --no-hook measures the operator without one")
     ap.add_argument("--scene", default=None, help="a trained scene file (.parquet in the reference's layout or an INRIA .ply) to "
                     "render instead of the synthetic generator's points; camera and resolution still come from --workload")
-    ap.add_argument("--views-per-rank", type=int, default=1,
+    ap.add_argument("--views-per-rank", type=int, default=None,
                     help="views each rank renders per step (gradients summed over them); a step then is V forward+backward passes "
-                         "and `value` counts views per second")
+                         "and `value` counts views per second.  Default: 1 on one GPU (the BASELINE metric); 4 with N > 1 in the "
+                         "view-parallel scheme, the gradient accumulation a data-parallel trainer uses to amortise the one "
+                         "all-reduce per step (DESIGN.md section 6)")
     ap.add_argument("--reduce", choices=["step", "view"], default="step",
                     help="view-parallel scheme with N > 1: 'step' = one all-reduce per step on the locally accumulated gradient; "
                          "'view' = one asynchronous all-reduce per view, overlapped with the next view's forward+backward")
@@ -108,7 +110,7 @@ def main():
         scene.point_cloud, scene.point_cloud_features = pc_np, ft_np
         scene.point_invalid_mask = np.zeros(pc_np.shape[0], np.int8)
         scene.point_object_id = np.zeros(pc_np.shape[0], np.int32)
-    V = max(1, args.views_per_rank)
+    V = max(1, args.views_per_rank) if args.views_per_rank is not None else (4 if (world > 1 and args.scheme == "view") else 1)
     n_views = world * V
     q, t = view_pose(rank * V, n_views)
     H, W = scene.height, scene.width

@@ -50,11 +50,11 @@ struct DevBuf {
 
 // What RAST:998-1019 saves for backward, in this library's layouts (DESIGN.md "HBM layout").
 struct FrameBufs {
-    DevBuf mask, ids, cam_index, rec, box, ntiles, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
+    DevBuf mask, ids, cam_index, rec, box, ntiles, depth_codes, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
     bool in_use = false;
     void release(int64_t* total)
     {
-        DevBuf* all[] = { &mask, &ids, &cam_index, &rec, &box, &ntiles, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
+        DevBuf* all[] = { &mask, &ids, &cam_index, &rec, &box, &ntiles, &depth_codes, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
                           &tile_start, &pose, &tile_order };
         for (DevBuf* b : all) b->release(total);
     }
@@ -359,7 +359,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     const size_t Np = (size_t)(N > 0 ? N : 1);
     ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
     ENSURE(B.rec, 64 * Np);
-    ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.offsets, 4 * Np);
+    ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.depth_codes, 4 * Np); ENSURE(B.offsets, 4 * Np);
     ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared together
     ENSURE(B.tile_order, 4 * (size_t)T);
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
@@ -376,7 +376,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.block_counts = c->block_counts.as<int32_t>(); pa.block_offsets = c->block_offsets.as<int32_t>();
     pa.ids = B.ids.as<int32_t>(); pa.cam_index = B.cam_index.as<int32_t>();
     set_records(pa, B, Np);
-    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
+    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
@@ -420,7 +420,7 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     ba.prof = &c->prof;
     ba.N = n_rows; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
-    ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.tile_block_offsets = pa.tile_block_offsets;
+    ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.depth_codes = pa.depth_codes; ba.tile_block_offsets = pa.tile_block_offsets;
     ba.block_offsets = pa.block_offsets; ba.block_counts = pa.block_counts;     // NULL for records that did not come from k_project
     ba.offsets = B.offsets.as<uint32_t>();
     ba.keys_a = B.keys_a.p; ba.keys_b = B.keys_b.p; ba.key64 = key64;
@@ -539,14 +539,14 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     const int T = tiles_x * tiles_y, H = cam->camera_height, W = cam->camera_width;
     const size_t Mp = (size_t)(m > 0 ? m : 1);
     const size_t nb = (size_t)((m + 255) / 256);
-    ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
+    ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.depth_codes, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
     ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * (size_t)T);
     ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
     if (m > 0) HIP_TRY_F(hipMemcpyAsync(B.rec.p, records, (size_t)m * 64, hipMemcpyDeviceToDevice, s));   // the frame keeps its own copy for backward
     GsProjectArgs pa{};
     pa.prof = &c->prof; pa.N = m; pa.H = H; pa.W = W; pa.depth_scale = cfg->depth_to_sort_key_scale;
     set_records(pa, B, Mp);
-    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>();
+    pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;

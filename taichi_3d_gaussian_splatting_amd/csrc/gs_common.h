@@ -188,6 +188,7 @@ struct GsProjectArgs {
     int H, W; float near_plane, far_plane, depth_scale;
     GsPose* pose; int8_t* mask; int32_t* block_counts; int32_t* block_offsets; int32_t* ids; int32_t* cam_index;
     float4 *PA, *PB, *PC, *PD; ushort4* box; int32_t* ntiles; uint32_t* tile_block_sums; uint32_t* tile_block_offsets;
+    int32_t* depth_codes;                       // (M) i32(depth * scale) per in-camera point, for the key build
     GsCounters* counters;
     int32_t* tile_arrays; int tile_ints;        // tile_start | tile_end | tile_work, cleared before the binning
     GsCounters* host_mirror; int32_t ticket;    // pinned host copy of the counters; .reserved = ticket once they are valid
@@ -200,7 +201,7 @@ void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s);
 struct GsBinArgs {
     GsProf* prof;
     int64_t N; int M; uint32_t K; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
-    const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const uint32_t* tile_block_offsets;
+    const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const int32_t* depth_codes; const uint32_t* tile_block_offsets;
     const int32_t *block_offsets, *block_counts;   // k_project's blocks (first in-camera offset, count); NULL: 256 consecutive records per block
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
     void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64

@@ -17,7 +17,7 @@
 #define KEYGEN_SMALL 12        // a lane writes up to this many pairs itself; larger splats are written by the wave
 
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, const ushort4* __restrict__ boxes,
+__global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ depth_codes, const ushort4* __restrict__ boxes,
                                                 const int32_t* __restrict__ ntiles,
                                                 const uint32_t* __restrict__ tile_block_offsets,
                                                 const int32_t* __restrict__ block_offsets, const int32_t* __restrict__ block_counts,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ PB, c
     if (valid) {
         offsets[idx] = off;
         bx = boxes[idx];
-        depth_code = (KeyT)(uint32_t)(int)(GS_REC(PB, idx).w * depth_scale);         // RAST:159-160
+        depth_code = (KeyT)(uint32_t)depth_codes[idx];                               // i32(depth * scale), RAST:159-160, from k_project
     }
     const int du = (int)bx.y - (int)bx.x, dv = (int)bx.w - (int)bx.z;
     // points with few tiles: a lane lists its pairs in LDS, then the wave writes all of them out together so that
@@ -307,7 +307,7 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     if (a.N == 0 || a.M == 0) return;
     const unsigned kg_blocks = a.block_offsets ? (unsigned)((a.N + 255) / 256) : (unsigned)((a.M + 255) / 256);
     GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<kg_blocks, 256, 0, s>>>(
-        a.PB, a.box, a.ntiles, a.tile_block_offsets, a.block_offsets, a.block_counts, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
+        a.depth_codes, a.box, a.ntiles, a.tile_block_offsets, a.block_offsets, a.block_counts, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
     if (a.K == 0) return;
     int nb, tpb;
     sort_geometry(a.K, &nb, &tpb);

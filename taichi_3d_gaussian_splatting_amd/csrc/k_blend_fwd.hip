@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
 {
     __shared__ float4 sRec[4][64][3];          // the batch's splat records, one slab per wave
     const int tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index as a scalar: LDS addresses of the wave's slab are then SGPR arithmetic + one v_mov instead of a 64-bit VALU mad per splat
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
     const int qx = tile_u * 16 + (wave & 1) * 8, qy = tile_v * 16 + (wave >> 1) * 8;
     const int pixel_u = qx + (lane & 7), pixel_v = qy + (lane >> 3);

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
                                                  float4* __restrict__ PA, float4* __restrict__ PB, float4* __restrict__ PC,
                                                  float4* __restrict__ PD, ushort4* __restrict__ boxes,
                                                  int32_t* __restrict__ ntiles, uint32_t* __restrict__ tile_block_sums,
-                                                 GsCounters* counters)
+                                                 GsCounters* counters, int32_t* __restrict__ depth_codes)
 {
     __shared__ int wave_sum[4];
     __shared__ int wave_max[4];
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         recD = make_float4(pcam[0], pcam[1], pcam[2], radii);
         boxes[idx] = make_ushort4((unsigned short)box[0], (unsigned short)box[1], (unsigned short)box[2], (unsigned short)box[3]);
         ntiles[idx] = count;
+        depth_codes[idx] = depth_code;          // for the key build: 4 bytes instead of a 64-byte record row per point
     }
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if GS_RS == 4
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
 __global__ __launch_bounds__(256) void k_boxes_from_records(const float4* __restrict__ PA, const float4* __restrict__ PB,
                                                             const float4* __restrict__ PD, int M, int W, int H, float depth_scale,
                                                             ushort4* __restrict__ boxes, int32_t* __restrict__ ntiles,
-                                                            uint32_t* __restrict__ tile_block_sums, GsCounters* counters)
+                                                            uint32_t* __restrict__ tile_block_sums, GsCounters* counters,
+                                                            int32_t* __restrict__ depth_codes)
 {
     __shared__ int wave_sum[4];
     __shared__ int wave_max[4];
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) void k_boxes_from_records(const float4* __rest
         depth_code = (int)(GS_REC(PB, idx).w * depth_scale);
         boxes[idx] = make_ushort4((unsigned short)box[0], (unsigned short)box[1], (unsigned short)box[2], (unsigned short)box[3]);
         ntiles[idx] = count;
+        depth_codes[idx] = depth_code;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sm = gs_wave_sum_i(count), mx = gs_wave_max_i(depth_code);
@@ -408,7 +411,7 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.mask, a.block_counts, a.N,
                                                               a.ids, a.cam_index, a.block_offsets, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
-                                                              a.tile_block_sums, a.counters));
+                                                              a.tile_block_sums, a.counters, a.depth_codes));
     GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
                                                                               a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
 }
@@ -421,7 +424,7 @@ void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s)
         return;
     }
     GS_TIMED(a.prof, KID_PROJECT, s, k_boxes_from_records<<<nb, 256, 0, s>>>(a.PA, a.PB, a.PD, M, a.W, a.H, a.depth_scale, a.box, a.ntiles,
-                                                                          a.tile_block_sums, a.counters));
+                                                                          a.tile_block_sums, a.counters, a.depth_codes));
     GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
                                                                               a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
 }
