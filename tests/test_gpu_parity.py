@@ -496,7 +496,10 @@ def test_soak_seeds_with_ill_conditioned_splats(P, seed):
         report[name] = r
         assert r["hip_vs_float64"] < 2e-5, (name, r)                   # the HIP result against exact arithmetic
         assert r["oracle_vs_float64"] < 2e-4, (name, r)                # the reference's f32 operation order against it
-    assert report["s"]["hip_vs_oracle"] > 1e-4 > 5 * report["s"]["hip_vs_float64"]      # this IS the oracle-limited case
+    # the signature of an oracle-limited case: HIP is several times closer to float64 than to the oracle, and the oracle is as far
+    # from float64 as it is from HIP (the HIP-oracle gap itself sits at the 1e-4 bar: 1.05e-4 and 1.14e-4 when this was written)
+    assert report["s"]["hip_vs_oracle"] > 5 * report["s"]["hip_vs_float64"]
+    assert report["s"]["oracle_vs_float64"] > 0.7 * report["s"]["hip_vs_oracle"]
     report["per_element_bar_use_vs_oracle"] = {k: v["bar_use_max"] for k, v in b["margins"].items()}
     os.makedirs(os.path.join(P.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(P.ROOT, "gpurun_out", f"soak_seed_{seed}.json"), "w") as fh:
