@@ -14,8 +14,13 @@
 
 #define SORT_TILE 4096          // keys per tile: 256 threads x 16
 #define SORT_ROUNDS 16
-#define KEYGEN_SMALL 12        // a lane writes up to this many pairs itself; larger splats are written by the wave
 
+// One lane per PAIR, not per point: a wave scans its 64 points' tile counts, keeps {first pair, tile box, depth code} of
+// every point in a small LDS table, and then walks the wave's pairs e = 0, 1, 2 ... 64 at a time -- lane l finds the
+// point that owns pair e (binary search over the 64 scanned counts), derives the tile from the pair's position in that
+// point's box (RAST:163-168: tile_u outer, tile_v inner) and stores key and value at slot wave_base + e.  The slots of a
+// wave are consecutive, so every store instruction writes 256 (or 512) consecutive bytes whatever the splat sizes are;
+// a splat covering thousands of tiles is simply many iterations in which all lanes find the same owner.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ depth_codes, const ushort4* __restrict__ boxes,
                                                 const int32_t* __restrict__ ntiles,
@@ -27,79 +32,55 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
                                                 int32_t* __restrict__ vals)
 {
     __shared__ uint32_t ws[4];
-    __shared__ KeyT sk[4][64 * KEYGEN_SMALL];        // pairs of the wave's small points: key, slot, point
-    __shared__ uint32_t ss[4][64 * KEYGEN_SMALL];
-    __shared__ int32_t sv[4][64 * KEYGEN_SMALL];
+    __shared__ uint32_t sExcl[4][64];
+    __shared__ ushort4 sBox[4][64];
+    __shared__ KeyT sCode[4][64];
     // same blocks as the kernel that produced ntiles / tile_block_offsets: k_project's (256 rows of the point cloud each, in-camera
     // points dense from block_offsets[b]) or, for records that arrived from elsewhere, 256 consecutive records
     const int first = block_offsets ? block_offsets[blockIdx.x] : (int)blockIdx.x * 256;
     const int mine = block_offsets ? block_counts[blockIdx.x] : min(256, M - first);
     const int idx = (int)threadIdx.x < mine ? first + (int)threadIdx.x : M;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t n = idx < M ? (uint32_t)ntiles[idx] : 0u;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool valid = idx < M;
+    const uint32_t n = valid ? (uint32_t)ntiles[idx] : 0u;
     uint32_t incl = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
     if (lane == 63) ws[wave] = incl;
+    sExcl[wave][lane] = incl - n;
+    sBox[wave][lane] = valid ? boxes[idx] : make_ushort4(0, 1, 0, 1);
+    sCode[wave][lane] = valid ? (KeyT)(uint32_t)depth_codes[idx] : (KeyT)0;     // i32(depth * scale), RAST:159-160, from k_project
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += ws[w];
-    const bool valid = idx < M;
-    const uint32_t off = tile_block_offsets[blockIdx.x] + woff + incl - n;
-    ushort4 bx = make_ushort4(0, 0, 0, 0);
-    KeyT depth_code = 0;
-    if (valid) {
-        offsets[idx] = off;
-        bx = boxes[idx];
-        depth_code = (KeyT)(uint32_t)depth_codes[idx];                               // i32(depth * scale), RAST:159-160, from k_project
-    }
-    const int du = (int)bx.y - (int)bx.x, dv = (int)bx.w - (int)bx.z;
-    // points with few tiles: a lane lists its pairs in LDS, then the wave writes all of them out together so that
-    // consecutive lanes store consecutive slots (a lane-per-run store pattern touches ~64 lines per instruction)
-    const uint32_t n_small = (valid && n <= KEYGEN_SMALL) ? n : 0u;
-    uint32_t sincl = n_small;
+    const uint32_t wave_base = tile_block_offsets[blockIdx.x] + woff;             // slot of the wave's first pair
+    if (valid) offsets[idx] = wave_base + incl - n;                               // RAST:913-922 (also the backward's row slots)
+    const uint32_t wave_total = ws[wave];
+    const int wave_first_point = first + (int)(threadIdx.x & ~63u);
+    for (uint32_t e = (uint32_t)lane; e < wave_total; e += 64u) {
+        int j = 0;                                                                // owner: the last point whose first pair is <= e
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(sincl, o, 64); if (lane >= o) sincl += t; }
-    const uint32_t wave_small = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
-    if (n_small) {
-        uint32_t e = sincl - n_small;
-        for (int tu = bx.x; tu < bx.y; ++tu)
-            for (int tv = bx.z; tv < bx.w; ++tv) {
-                const uint32_t slot = off + (uint32_t)(dv * (tu - bx.x) + (tv - bx.z));   // RAST:163-166
-                const KeyT tile_id = (KeyT)(tu + tv * tiles_x);                           // RAST:167-168
-                sk[wave][e] = (tile_id << depth_bits) | depth_code;
-                ss[wave][e] = slot;
-                sv[wave][e] = idx;
-                ++e;
-            }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t e = lane; e < wave_small; e += 64) {
-        const uint32_t slot = ss[wave][e];
-        if (slot < K_cap) { keys[slot] = sk[wave][e]; vals[slot] = sv[wave][e]; }
-    }
-    // points with many tiles: the wave writes them together, 64 consecutive slots per step
-    unsigned long long big = gs_ballot(valid && n > KEYGEN_SMALL);
-    while (big) {
-        const int j = __builtin_ctzll(big);
-        big &= big - 1ull;
-        const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
-        const int bn = __builtin_amdgcn_readlane((int)n, j);
-        const int bu0 = __builtin_amdgcn_readlane((int)bx.x, j), bv0 = __builtin_amdgcn_readlane((int)bx.z, j);
-        const int bdv = __builtin_amdgcn_readlane(dv, j);
-        const uint32_t bcode = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)depth_code, j);
-        const int bidx = first + (int)(threadIdx.x & ~63) + j;
-        for (int t = lane; t < bn; t += 64) {
-            const int tu = bu0 + t / bdv, tv = bv0 + t % bdv;                       // slot order: tile_u outer, tile_v inner
-            const uint32_t slot = boff + (uint32_t)t;
-            if (slot < K_cap) {
-                KeyT tile_id = (KeyT)(tu + tv * tiles_x);
-                keys[slot] = (tile_id << depth_bits) | (KeyT)bcode;
-                vals[slot] = bidx;
-            }
+        for (int step = 32; step > 0; step >>= 1) if (sExcl[wave][j + step] <= e) j += step;
+        const uint32_t t = e - sExcl[wave][j];                                    // position in the owner's box
+        const ushort4 bx = sBox[wave][j];
+        const uint32_t dv = (uint32_t)((int)bx.w - (int)bx.z);
+        // t / dv: float estimate + one correction step either way (exact below 2^22; a box has at most tiles_x * tiles_y entries)
+        uint32_t tq, tr;
+        if (t < (1u << 22)) {
+            tq = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)dv));
+            int r = (int)t - (int)(tq * dv);
+            if (r < 0) { tq -= 1u; r += (int)dv; }
+            if (r >= (int)dv) { tq += 1u; r -= (int)dv; }
+            tr = (uint32_t)r;
+        } else { tq = t / dv; tr = t - tq * dv; }
+        const KeyT tile_id = (KeyT)(((uint32_t)bx.x + tq) + ((uint32_t)bx.z + tr) * (uint32_t)tiles_x);   // RAST:163-168
+        const uint32_t slot = wave_base + e;
+        if (slot < K_cap) {
+            keys[slot] = (tile_id << depth_bits) | sCode[wave][j];               // RAST:169-170, compact form
+            vals[slot] = wave_first_point + j;
         }
     }
-    (void)du;
+    (void)depth_scale;
 }
 
 template <typename KeyT>
