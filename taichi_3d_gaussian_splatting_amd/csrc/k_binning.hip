@@ -12,8 +12,10 @@
 #include "gs_common.h"
 #include <type_traits>
 
-#define SORT_TILE 4096          // keys per tile: 256 threads x 16
+#ifndef SORT_ROUNDS
 #define SORT_ROUNDS 16
+#endif
+#define SORT_TILE (256 * SORT_ROUNDS)          // keys per tile: 256 threads x SORT_ROUNDS
 
 // One lane per PAIR, not per point: a wave scans its 64 points' tile counts, keeps {first pair, tile box, depth code} of
 // every point in a small LDS table, and then walks the wave's pairs e = 0, 1, 2 ... 64 at a time -- lane l finds the
