@@ -43,11 +43,29 @@ __device__ __forceinline__ CullSplat gs_cull_prepare(float4 A, float4 B, float4 
     return s;
 }
 
-// true when the splat cannot reach alpha >= 1/255 anywhere in the 8x8 rectangle whose first pixel
-// centre is (rx0, ry0).  Any NaN makes the test false (= keep the splat).
-__device__ __forceinline__ bool gs_cull(const CullSplat& s, float rx0, float ry0)
+// The rectangle of an 8x8 quadrant's pixels that are still of interest (wave-uniform, from a 64-bit lane mask with
+// lane = 8 * row + column): first column / row and extent in pixels.  A splat only has to be kept if it can reach
+// 1/255 at one of THOSE pixels -- the others have saturated (forward) or lie beyond their last contributor (backward)
+// and take nothing from it -- so the cull rectangle shrinks with the mask and the late part of a walk, where a few
+// pixels keep a wave going, evaluates a fraction of the splats.  Exactly as invisible in the results as the quadrant cull.
+struct CullRect { float x0, y0, wx, wy; };
+__device__ __forceinline__ CullRect gs_live_rect(unsigned long long mask, float qx0, float qy0)
 {
-    const float X0 = rx0 - s.u, X1 = X0 + 7.0f, Y0 = ry0 - s.v, Y1 = Y0 + 7.0f;
+    // rows: which bytes of the mask are non-zero; columns: the OR of the eight bytes
+    const int ymin = __builtin_ctzll(mask) >> 3, ymax = (63 - __builtin_clzll(mask)) >> 3;
+    uint32_t c = (uint32_t)mask | (uint32_t)(mask >> 32);
+    c |= c >> 16; c |= c >> 8; c &= 0xffu;
+    const int xmin = __builtin_ctz(c), xmax = 31 - __builtin_clz(c);
+    CullRect r;
+    r.x0 = qx0 + (float)xmin; r.y0 = qy0 + (float)ymin; r.wx = (float)(xmax - xmin); r.wy = (float)(ymax - ymin);
+    return r;
+}
+
+// true when the splat cannot reach alpha >= 1/255 anywhere in the rectangle of pixel centres [rx0, rx0 + wx] x [ry0, ry0 + wy]
+// (wx = wy = 7: a whole 8x8 quadrant whose first pixel centre is (rx0, ry0)).  Any NaN makes the test false (= keep the splat).
+__device__ __forceinline__ bool gs_cull(const CullSplat& s, float rx0, float ry0, float wx = 7.0f, float wy = 7.0f)
+{
+    const float X0 = rx0 - s.u, X1 = X0 + wx, Y0 = ry0 - s.v, Y1 = Y0 + wy;
     const float ax = fmaxf(fabsf(X0), fabsf(X1)), ay = fmaxf(fabsf(Y0), fabsf(Y1));
     // rounding slack of the f32 exponent evaluated per pixel (terms can cancel for skewed conics)
     const float slack = 0.02f + (s.sa * ax * ax + s.sc * ay * ay + s.sb * ax * ay);

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
             unsigned long long U = 0ull;
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
-                mq[qi] = gs_ballot(valid && i < qlast[qi] && !gs_cull(cs, rx0[qi], ry0[qi]));
+                // pixels of the quadrant some entry of this batch is still in range for (RAST:609-610)
+                const unsigned long long inq = gs_ballot(Q[qi].last > lo);
+                if (inq == 0ull) { mq[qi] = 0ull; continue; }
+                const CullRect lr = gs_live_rect(inq, rx0[qi], ry0[qi]);
+                mq[qi] = gs_ballot(valid && i < qlast[qi] && !gs_cull(cs, lr.x0, lr.y0, lr.wx, lr.wy));
                 U |= mq[qi];
             }
             GS_STAT(8, 1);

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
         const bool valid = i < end;
         const int p = valid ? sorted_vals[i] : 0;
         float4 A = GS_REC(PA, p), B = GS_REC(PB, p), C = GS_REC(PC, p);
-        bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), rx0, ry0);
+        const CullRect lr = gs_live_rect(alive, rx0, ry0);          // the pixels that have not saturated yet
+        bool keep = valid && !gs_cull(gs_cull_prepare(A, B, C), lr.x0, lr.y0, lr.wx, lr.wy);
         unsigned long long mask = gs_ballot(keep);
         GS_STAT(0, 1); GS_STAT(1, __popcll(mask));
         if (mask == 0ull) continue;
