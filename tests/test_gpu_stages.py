@@ -220,3 +220,30 @@ def test_loss_function_accepts_a_batch(P):
     assert abs(float(L) - 0.5 * (float(singles[0][0]) + float(singles[1][0]))) < 1e-6
     assert abs(float(L1) - float(torch.abs(a - b).mean())) < 1e-6
     assert abs(float(LD) - 0.5 * (float(singles[0][2]) + float(singles[1][2]))) < 1e-6
+
+
+def test_staged_entry_points_reject_frames_of_the_wrong_kind(P):
+    """gs_backward needs a gs_forward frame, gs_backward_projected a frame with the raster stage, gs_backward_shard one with the
+    projection stage; a frame that was not kept cannot be back-propagated at all (GS_ERR_STATE = -4 through the C ABI)."""
+    L = _native.lib()
+    s = synth(800, 64, 64, 0.1, seed=57)
+    q, t = view_pose()
+    st = StagedRasteriser()
+    inp = P.make_input(s, q, t, 3, requires_grad=False)
+    rec, ids, pframe = st.project_shard(inp)
+    outs, rframe = st.forward_projected(rec, inp.camera_info)
+    g = torch.ones_like(outs.rasterized_image)
+    with pytest.raises(RuntimeError, match="raster stage"):
+        st.backward_projected(pframe, outs, g)                    # a projection-only frame has nothing to blend backwards
+    sums, _ = st.backward_projected(rframe, outs, g)
+    with pytest.raises(RuntimeError, match="projection stage"):
+        st.backward_shard(rframe, inp, sums)                      # and a raster-only frame knows no point cloud
+    with pytest.raises(ValueError):
+        st.backward_shard(pframe, inp, sums[:-1])                 # wrong number of rows
+    rec2, ids2, transient = st.project_shard(inp, keep=False)
+    with pytest.raises(RuntimeError, match="not kept"):
+        st.backward_shard(transient, inp, sums)
+    with pytest.raises(TypeError):
+        st.forward_projected(rec.double(), inp.camera_info)
+    gr = st.backward_shard(pframe, inp, sums)                     # the right pairing still works afterwards
+    assert gr.grad_pointcloud.shape == (800, 3)
