@@ -83,6 +83,7 @@ typedef struct gso_frame {
  * the HIP kernels implement the same operation sequence so index-determining
  * thresholds agree bit for bit. */
 float gso_expf(float x);
+float gso_exp_blend(float x);
 
 /* RAST:845 + UTIL:396-432  (inverse_SE3_qt_torch) */
 void gso_inverse_se3_qt(const float* q, const float* t, int n, float* q_inv, float* t_inv);

@@ -75,6 +75,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.gso_expf.restype = C.c_float
         L.gso_expf.argtypes = [C.c_float]
+        L.gso_exp_blend.restype = C.c_float
+        L.gso_exp_blend.argtypes = [C.c_float]
         L.gso_forward.restype = C.POINTER(_Frame)
         L.gso_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
@@ -110,6 +112,13 @@ def _p(a):
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def exp_blend(x):
+    """gso_exp_blend: the exp of the two blend loops (cheaper sequence than gso_expf, same accuracy on [-10, 0])."""
+    L = lib()
+    x = np.asarray(x, dtype=np.float32)
+    return np.array([L.gso_exp_blend(float(v)) for v in x.ravel()], dtype=np.float32).reshape(x.shape)
 
 
 def expf(x):

@@ -79,6 +79,27 @@ __device__ __forceinline__ float gs_expf(float x)
     return __int_as_float(bits);
 }
 
+// exp of the Gaussian falloff in the blend kernels (oracle: gso_exp_blend, same sequence bit for bit): eleven VALU
+// instructions where gs_expf takes seventeen.  2^(x log2 e): integer part through the 1.5*2^23 constant, fraction with one
+// fused multiply-add (the rounding of x*log2(e) does not enter), degree-5 polynomial for 2^f on [-0.5, 0.5], the integer
+// added to the exponent field (v_lshl_add_u32).  Within 3e-7 of exp for x in [-10, 0].
+__device__ __forceinline__ float gs_exp_blend(float x)
+{
+    x = __builtin_amdgcn_fmed3f(x, -86.0f, 88.0f);
+    const float L = 1.44269504088896341f;
+    const float t = x * L;
+    const float m = t + 12582912.0f;
+    const float n = m - 12582912.0f;
+    const float f = __builtin_fmaf(x, L, -n);
+    float q = 0.0013264712179079652f;
+    q = __builtin_fmaf(q, f, 0.009671511128544807f);
+    q = __builtin_fmaf(q, f, 0.05550733581185341f);
+    q = __builtin_fmaf(q, f, 0.24022242426872253f);
+    q = __builtin_fmaf(q, f, 0.6931470036506653f);
+    const float p = __builtin_fmaf(q, f, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(m) << 23));
+}
+
 __device__ __forceinline__ float gs_sigmoid(float x) { return 1.0f / (1.0f + gs_expf(-x)); }
 
 // C[r x c] = A[r x k] @ B[k x c]; terms summed k = 0,1,2,... like the Python matmul chain.

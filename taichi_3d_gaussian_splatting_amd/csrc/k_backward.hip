@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         float prod_alpha = g * apt;
                         if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
                             const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
-                            g = gs_expf(-0.5f * (dx * sx + dy * sy)) * b4.y;
+                            g = gs_exp_blend(-0.5f * (dx * sx + dy * sy)) * b4.y;
                             prod_alpha = g * apt;
                             GS_STAT(14, 1);
                         }

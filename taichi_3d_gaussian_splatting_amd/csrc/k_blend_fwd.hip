@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
             float dx = px - a4.x, dy = py - a4.y;
             float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
             GS_STAT(2, 1);
-            float g = gs_expf(exponent) * b4.y;
+            float g = gs_exp_blend(exponent) * b4.y;
             float alpha = g * b4.z;
             unsigned long long use_m = gs_ballot(!(alpha < GS_ALPHA_EPS)) & alive;    // RAST:451
             alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                // RAST:453

@@ -13,6 +13,21 @@ def test_expf_accuracy():
     assert np.max(np.abs(got - ref) / ref) < 2.5e-7     # <= 2 ulp of f32
 
 
+def test_exp_blend_accuracy():
+    # the falloff's exp: alpha >= 1/255 needs an exponent >= -5.6, the cull keeps a little more
+    x = np.concatenate([np.linspace(-10, 0, 40001), -np.logspace(-8, 1, 4001)]).astype(np.float32)
+    got = oracle.exp_blend(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 3.5e-7
+    assert oracle.exp_blend(np.float32(0.0)) == np.float32(1.0)
+    assert np.all(np.diff(oracle.exp_blend(np.linspace(-10, 0, 40001).astype(np.float32))) >= 0)      # monotone on the grid
+    # the whole clamped range stays finite and close (the integer part is added to the exponent field)
+    x = np.linspace(-120, 100, 22001).astype(np.float32)
+    got = oracle.exp_blend(x).astype(np.float64)
+    ref = np.exp(np.clip(x.astype(np.float64), -86, 88))
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got - ref) / ref) < 2e-6
+
+
 def test_find_tile_start_and_end_known_answer(golden):
     g = golden["find_tile_start_and_end"]          # reference tests :19-42, exact ints
     ts, te = oracle.find_tile_start_and_end(np.array(g["keys"], np.int64), g["n_tiles"])
