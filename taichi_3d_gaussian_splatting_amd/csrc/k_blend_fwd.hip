@@ -95,32 +95,52 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
         evals += __popcll(mask);
         sRec[wave][lane][0] = A; sRec[wave][lane][1] = B; sRec[wave][lane][2] = C;
         __builtin_amdgcn_wave_barrier();
+        // Two splats per trip: their alphas are independent (two dependency chains to interleave: a quadrant's walk is
+        // otherwise one long chain of dependent instructions, and the end of the launch runs with few waves per SIMD
+        // to hide it behind), the two blend steps then run in list order.  Same operations per splat as one at a time.
         while (mask) {
-            const int j = __builtin_ctzll(mask);
+            const int j0 = __builtin_ctzll(mask);
             mask &= mask - 1ull;
-            const float4 a4 = sRec[wave][j][0], b4 = sRec[wave][j][1], c4 = sRec[wave][j][2];
+            const bool two = mask != 0ull;                                      // wave-uniform
+            const int j1 = two ? __builtin_ctzll(mask) : j0;
+            mask &= mask - 1ull;                                                // 0 stays 0
+            const float4 a40 = sRec[wave][j0][0], b40 = sRec[wave][j0][1], c40 = sRec[wave][j0][2];
+            const float4 a41 = sRec[wave][j1][0], b41 = sRec[wave][j1][1], c41 = sRec[wave][j1][2];
             // get_point_probability_density_from_conic_and_rescale, UTIL:275-284 (same op order)
-            float dx = px - a4.x, dy = py - a4.y;
-            float exponent = -0.5f * (dx * dx * a4.z + dy * dy * b4.x) - dx * dy * a4.w;
-            GS_STAT(2, 1);
-            float g = gs_exp_blend(exponent) * b4.y;
-            float alpha = g * b4.z;
-            unsigned long long use_m = gs_ballot(!(alpha < GS_ALPHA_EPS)) & alive;    // RAST:451
-            alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                // RAST:453
-            float next_T = T_i * (1.0f - alpha);                                // RAST:457
-            const unsigned long long sat_m = gs_ballot(next_T < GS_T_STOP) & use_m;   // RAST:458-460
-            alive &= ~sat_m;
-            use_m &= ~sat_m;
-            GS_STAT(3, __popcll(use_m)); GS_STAT(5, __popcll(alive));
-            if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {
-                last = base + j + 1;                                            // RAST:461
-                // alpha and T (and with them every index the forward returns) follow the reference operation sequence bit
-                // for bit; the weighted sums use one shared weight and fused multiply-adds (float outputs, 1e-4 bar)
-                const float w = alpha * T_i;
-                cr = __builtin_fmaf(c4.x, w, cr); cg = __builtin_fmaf(c4.y, w, cg); cb = __builtin_fmaf(c4.z, w, cb);   // RAST:462
-                if (!RGB_ONLY) { acc_d = __builtin_fmaf(b4.w, w, acc_d); norm += w; count += 1; }                    // RAST:464-469
-                T_i = next_T;
+            const float dx0 = px - a40.x, dy0 = py - a40.y, dx1 = px - a41.x, dy1 = py - a41.y;
+            const float e0 = -0.5f * (dx0 * dx0 * a40.z + dy0 * dy0 * b40.x) - dx0 * dy0 * a40.w;
+            const float e1 = -0.5f * (dx1 * dx1 * a41.z + dy1 * dy1 * b41.x) - dx1 * dy1 * a41.w;
+            float alpha0 = gs_exp_blend(e0) * b40.y * b40.z;
+            float alpha1 = gs_exp_blend(e1) * b41.y * b41.z;
+            // both alphas are complete HERE: without this the compiler sinks the second chain below the first blend step
+            // (next to its only use) and the two run one after the other
+            asm volatile("" : "+v"(alpha0), "+v"(alpha1));
+#define GS_FWD_STEP(ALPHA, A4, B4, C4, J, LIVE)                                                                                        \
+            {                                                                                                                    \
+                GS_STAT(2, 1);                                                                                                   \
+                float alpha = (ALPHA);                                                                                           \
+                unsigned long long use_m = gs_ballot(!(alpha < GS_ALPHA_EPS)) & (LIVE);   /* RAST:451 */                          \
+                alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                      /* RAST:453 */                          \
+                const float next_T = T_i * (1.0f - alpha);                                /* RAST:457 */                          \
+                const unsigned long long sat_m = gs_ballot(next_T < GS_T_STOP) & use_m;   /* RAST:458-460 */                      \
+                alive &= ~sat_m;                                                                                                 \
+                use_m &= ~sat_m;                                                                                                 \
+                GS_STAT(3, __popcll(use_m)); GS_STAT(5, __popcll(alive));                                                        \
+                if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                                                                \
+                    last = base + (J) + 1;                                                /* RAST:461 */                          \
+                    /* alpha and T (and with them every index the forward returns) follow the reference operation sequence   */ \
+                    /* bit for bit; the weighted sums use one shared weight and fused multiply-adds (float outputs, 1e-4 bar) */ \
+                    const float w = alpha * T_i;                                                                                 \
+                    cr = __builtin_fmaf((C4).x, w, cr); cg = __builtin_fmaf((C4).y, w, cg); cb = __builtin_fmaf((C4).z, w, cb);  /* RAST:462 */ \
+                    if (!RGB_ONLY) { acc_d = __builtin_fmaf((B4).w, w, acc_d); norm += w; count += 1; }   /* RAST:464-469 */      \
+                    T_i = next_T;                                                                                                \
+                }                                                                                                                \
             }
+            GS_FWD_STEP(alpha0, a40, b40, c40, j0, alive)
+            // no branch around the second step (a missing second splat just has no live lanes): its alpha is then needed
+            // unconditionally and the compiler keeps the two alpha chains in one block, where it interleaves them
+            GS_FWD_STEP(alpha1, a41, b41, c41, j1, two ? alive : 0ull)
+#undef GS_FWD_STEP
             if (alive == 0ull) mask = 0ull;
         }
         __builtin_amdgcn_wave_barrier();
