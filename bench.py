@@ -278,7 +278,7 @@ def main():
                     simd_cycles = avg_ms * 1e-3 * 2.4e9 * 1024
                     # issue cost of the kernel's own instruction mix on a perfectly fed SIMD (tools/ubench_valu.hip: plain 2.5 cycles,
                     # DPP / compare-class 4.2, transcendental 8.2; mixes counted from the ISA)
-                    floor = {"k_blend_bwd_tile": 3.0, "k_blend_fwd": 2.7}.get(dominant)
+                    floor = {"k_blend_bwd_tile": 3.0, "k_blend_fwd": 2.6}.get(dominant)
                     valu = {"wave_valu_instructions_per_launch": insts, "simd_cycles_per_launch": round(simd_cycles),
                             "cycles_per_valu_instruction": round(simd_cycles / insts, 3),
                             "issue_floor_cycles_per_instruction": floor,
