@@ -304,6 +304,9 @@ def main():
                                        if args.scheme == "gaussian" else
                                        f"view-parallel x{world}, {V} view(s) per rank per step, all-reduce per {args.reduce}"),
                        "views_per_rank": V, "views_per_step": world * V,
+                       "forward_dispatch_order": ("natural (GS_FWD_ORDER_HINT=0)" if os.environ.get("GS_FWD_ORDER_HINT", "1")[:1] == "0" or mode != "fwdbwd"
+                                                  else "tile order left by the previous backward of this context (scheduling only; "
+                                                       + ("the same pose every step here" if V == 1 else f"{V} poses cycled") + ")"),
                        "collectives_per_step": (gp_stats.get("collectives", 0) if args.scheme == "gaussian" else (ncoll[-1] if ncoll else 0)),
                        "exchange_bytes_sent_per_rank_per_step": (gp_stats.get("bytes_sent") if args.scheme == "gaussian"
                                                                  else (0 if world == 1 else 236 * N * (V if args.reduce == "view" else 1))),

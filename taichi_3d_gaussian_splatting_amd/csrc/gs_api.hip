@@ -116,6 +116,10 @@ struct gs_ctx {
     GsCounters* host_counters = nullptr;   // pinned, device-visible; written by k_scan_tiles_publish
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
     int32_t ticket = 0;                    // sequence number of the last forward
+    // dispatch order for the next forward blend: the last backward's tile order (heaviest first).  Only ever a complete
+    // permutation of [0, order_hint_T) written by k_tile_order; 0 = none.  A hint only moves work in time.
+    DevBuf order_hint;
+    int order_hint_T = 0;
     // stream hand-over: the scratch above is recycled in stream order, so work arriving on another stream waits for
     // everything issued on the previous one
     bool has_stream = false;
@@ -162,7 +166,7 @@ extern "C" int gs_destroy(gs_ctx* c)
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
     for (Frame* f : c->frames) delete f;
     DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
-                      &c->counters, &c->partial, &c->visited, &c->sums, &c->loss_ws };
+                      &c->counters, &c->partial, &c->visited, &c->sums, &c->loss_ws, &c->order_hint };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
@@ -440,6 +444,8 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
     fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;
     fa.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)T;
+    static const bool use_hint = []{ const char* e = getenv("GS_FWD_ORDER_HINT"); return !(e && e[0] == '0'); }();
+    fa.order_hint = (use_hint && c->order_hint_T == T && T > 0) ? c->order_hint.as<int32_t>() : nullptr;
     // tile ranges are all zero when K == 0, so the kernel writes the "no contributor" values itself
     gs_launch_blend_fwd(fa, s);
     HIP_TRY_F(hipGetLastError());
@@ -664,9 +670,15 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     const size_t Mp = (size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1);
     e = c->visited.ensure(flag_bytes + 64 + Mp + 16, &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: visited buffer");
+    if (c->order_hint_T != f->info.n_tiles) {          // another tile grid: the old ordering is void from here on
+        c->order_hint_T = 0;
+        if (c->order_hint.ensure(4 * (size_t)(f->info.n_tiles > 0 ? f->info.n_tiles : 1), &c->device_bytes) != hipSuccess)
+            return fail(GS_ERR_OUT_OF_MEMORY, "backward: tile order buffer");
+    }
     const FrameBufs& B = *f->bufs;
     GsBackwardArgs a{};
     a.prof = &c->prof;
+    a.order_hint = c->order_hint.as<int32_t>();
     a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = K;
     a.H = f->info.camera_height; a.W = f->info.camera_width; a.T = f->info.n_tiles;
     a.tiles_x = (a.W + GS_TILE - 1) / GS_TILE;
@@ -753,6 +765,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* h, const gs_scene* sc, const gs_
     if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), &a)) != GS_OK) return rc;
     if ((rc = prepare_backward_points(f, sc, cam, cfg, sh_band, out, c->sums.as<float4>(), &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
+    if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
     gs_launch_backward_points(a, s);
     HIP_TRY(hipGetLastError());
     return GS_OK;
@@ -777,6 +790,7 @@ extern "C" int gs_backward_projected(gs_ctx* c, gs_frame* h, const float* grad_i
     int rc;
     if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
+    if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }

@@ -245,6 +245,7 @@ struct GsBlendFwdArgs {
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
     int32_t* tile_work;            // (T) zeroed together with the tile ranges; max over the tile's pixels of last - start
+    const int32_t* order_hint;     // (T) or NULL: a permutation of the tiles, heaviest first, from an earlier frame of this ctx (scheduling only)
 };
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
 
@@ -253,6 +254,7 @@ struct GsBackwardArgs {
     int64_t N; int M; uint32_t K; int H, W, tiles_x, T;
     const int32_t *tile_start, *tile_end; const int32_t* vals_sorted;
     const int32_t* tile_work; int32_t* tile_order;   // scheduling: heaviest tiles first
+    int32_t* order_hint;                             // (T) or NULL: a second copy of tile_order that outlives the frame (the next forward's dispatch order)
     const float4 *PA, *PB, *PC, *PD; const ushort4* box; const uint32_t* offsets; const int32_t* ntiles;
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;

@@ -39,7 +39,7 @@
 // not depend on it.  Work = the (splat, quadrant) evaluations the forward counted for the tile.
 #define ORDER_BINS 2048
 #define ORDER_BIN_WIDTH 4
-__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order,
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,
                                                      uint4* __restrict__ clear, size_t clear_vec)
 {
     __shared__ uint32_t bins[ORDER_BINS];
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
         int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
         const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
         order[pos] = i;
+        if (hint) hint[pos] = i;
     }
 }
 
@@ -639,7 +640,7 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         // workgroup 0 orders the tiles, the rest clear the flags + the shared all-zero row behind them (16-byte units)
         const size_t clear_vec = (a.visited_bytes + 15) / 16;
         const unsigned clear_groups = (unsigned)((clear_vec + 4095) / 4096 < 1024 ? (clear_vec + 4095) / 4096 : 1024);
-        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order,
+        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint,
                                                                                          reinterpret_cast<uint4*>(a.visited), clear_vec));
         if (a.G == 1)
             GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,

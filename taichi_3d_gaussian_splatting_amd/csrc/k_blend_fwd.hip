@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
                                                    const float4* __restrict__ PC, int W, int H, int tiles_x,
                                                    float* __restrict__ image, float* __restrict__ depth_out,
                                                    float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
-                                                   int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work)
+                                                   int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work,
+                                                   const int32_t* __restrict__ order_hint)
 {
     __shared__ float4 sRec[4][64][3];          // the batch's splat records, one slab per wave
-    const int tile = blockIdx.x;
+    // Dispatch order: heaviest tiles first when an earlier frame of this context left its ordering (same tile count) -- the
+    // launch otherwise ends on the long walks of the image's dense region, started late.  Any permutation gives the same results.
+    const int tile = order_hint ? order_hint[blockIdx.x] : (int)blockIdx.x;
     // the wave index as a scalar: LDS addresses of the wave's slab are then SGPR arithmetic + one v_mov instead of a 64-bit VALU mad per splat
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
@@ -167,8 +170,8 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
     if (a.T <= 0) return;
     if (a.rgb_only)
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
-                                                                             a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
+                                                                             a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
     else
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
-                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work));
+                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
 }

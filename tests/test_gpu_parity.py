@@ -144,6 +144,37 @@ def test_backward_is_bitwise_reproducible(P):
     assert np.array_equal(grads[0][1].view(np.uint32), grads[1][1].view(np.uint32))
 
 
+def test_dispatch_order_hint_from_an_earlier_frame_changes_nothing(P):
+    """A context keeps the last backward's tile order (heaviest first) as the dispatch order of its next forward blend
+    (gs_api.hip: order_hint).  Pure scheduling: a frame rendered after a backward at ANOTHER pose (a hint that does not fit), at
+    the same pose, or on a fresh context (no hint) gives the same bits, forward and backward; a change of the tile grid drops it."""
+    s = synth(30000, 256, 192, 0.05, seed=5)
+    q, t = view_pose()
+    q2, t2 = view_pose(3, 8)
+
+    def run(module, qq, tt):
+        inp = P.make_input(s, qq, tt)
+        img, depth, count = module(inp)
+        (img * img).sum().backward()
+        return [x.detach().cpu().numpy().copy() for x in (img, depth, count, inp.point_cloud.grad, inp.point_cloud_features.grad)]
+
+    fresh = run(P.Rast(P.Rast.GaussianPointCloudRasterisationConfig()), q, t)
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    run(module, q2, t2)                      # leaves the ordering of another view behind
+    other = run(module, q, t)                # rendered with that ordering
+    same = run(module, q, t)                 # rendered with its own ordering
+    small = synth(500, 64, 64, 0.1, seed=6)  # another tile grid on the same context: the hint must not be used
+    inp = P.make_input(small, q, t)
+    img_small = module(inp)[0]
+    (img_small * img_small).sum().backward()
+    ref_small = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())(P.make_input(small, q, t, requires_grad=False))[0]
+    assert np.array_equal(img_small.detach().cpu().numpy().view(np.uint32), ref_small.cpu().numpy().view(np.uint32))
+    back = run(module, q, t)                 # back to the first grid: no stale ordering either
+    for got in (other, same, back):
+        for a, b in zip(got, fresh):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
 def test_argument_errors(P):
     s = synth(16, 64, 64, 0.1)
     q, t = view_pose()
