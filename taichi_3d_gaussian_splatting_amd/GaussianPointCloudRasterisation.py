@@ -48,12 +48,29 @@ def _require(t: torch.Tensor, name: str, dtype, shape_tail, device=None):
         raise ValueError(f"{name} must have shape (*, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}")
 
 
+class _on_device:
+    """torch.cuda.device(dev) only when dev is not already current (the context manager costs microseconds per call)."""
+
+    def __init__(self, dev):
+        self._cm = None if dev.index is None or torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._cm is not None:
+            self._cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self._cm is not None:
+            return self._cm.__exit__(*exc)
+        return False
+
+
 class _Frame:
     """Owner of a gs_frame ticket: what ctx.save_for_backward keeps in the reference (RAST:998-1021).  Holds the
     context alive (the ticket is meaningless without it) and gives the ticket back when it dies."""
 
     def __init__(self, context: "_native.Context", handle, device, owned=True):
         self._context, self._h, self.device, self._owned = context, handle, device, owned
+        self.marshalled = None              # (gs_scene, gs_camera, gs_config) of the forward that made the frame
         info = _native.GsFrameInfo()
         _native.check(_native.lib().gs_frame_get_info(context.handle, self._h, C.byref(info)), "gs_frame_get_info")
         self.n_points, self.n_points_in_camera, self.n_keys = info.n_points, info.n_points_in_camera, info.n_keys
@@ -218,6 +235,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
     def _c_camera(q, t, camera_info, Kmat):
         return _native.GsCamera(_ptr(q), _ptr(t), q.shape[0], _ptr(Kmat), camera_info.camera_height, camera_info.camera_width)
 
+    def _marshal(self, pointcloud, features, mask, obj, q, t, camera_info):
+        Kmat = self._validate(pointcloud, features, mask, obj, q, t, camera_info)
+        return self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
+
     def _validate(self, pointcloud, features, mask, obj, q, t, camera_info):
         dev = pointcloud.device
         _require(pointcloud, "point_cloud", torch.float32, (3,))
@@ -253,10 +274,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         frame_h = C.c_void_p()
         scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(_native.lib().gs_forward(ctxh, C.byref(scene), C.byref(cam), C.byref(cfg), C.byref(out),
                                                    1 if keep else 0, C.byref(frame_h), C.c_void_p(stream)), "gs_forward")
         frame = _Frame(context, frame_h, dev, owned=keep)
+        if keep:
+            frame.marshalled = (scene, cam, cfg)       # the backward of this frame reads the same tensors (Kmat is kept alive below)
+            frame._keepalive = Kmat
         self.last_frame = frame
         self.last_forward_outputs = {"pixel_accumulated_alpha": acc_alpha, "pixel_offset_of_last_effective_point": last}
         return (image, depth, acc_alpha, last, count), frame
@@ -265,7 +289,16 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         dev = pointcloud.device
         N, M = pointcloud.shape[0], frame.n_points_in_camera
         H, W = camera_info.camera_height, camera_info.camera_width
-        Kmat = self._validate(pointcloud, features, mask, obj, q, t, camera_info)
+        # The host part of a backward sits on the step's critical path (the GPU has about one forward blend of queued work
+        # when autograd gets here), so it is kept short: the inputs were validated and marshalled by the forward of this
+        # frame (same tensors: autograd's saved tensors), and everything the hook receives comes out of ONE allocation.
+        ms = frame.marshalled
+        if ms is None or (ms[0].point_cloud, ms[0].point_cloud_features, ms[0].point_invalid_mask, ms[0].point_object_id, ms[0].n_points,
+                          ms[1].q_pointcloud_camera, ms[1].t_pointcloud_camera) != (
+                pointcloud.data_ptr() or None, features.data_ptr() or None, mask.data_ptr() or None, obj.data_ptr() or None, pointcloud.shape[0],
+                q.data_ptr() or None, t.data_ptr() or None):
+            ms = self._marshal(pointcloud, features, mask, obj, q, t, camera_info)     # storage was swapped since the forward (p.data = ...)
+        scene, cam, cfg = ms
         if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (H, W, 3):
             raise ValueError("grad of rasterized_image must be float32 (H,W,3)")
         # one allocation for both gradients so that data-parallel training all-reduces ONE buffer; the 56-float rows
@@ -274,19 +307,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         grad_feat = flat[:N * 56].view(N, 56)
         grad_pc = flat[N * 56:].view(N, 3)
         want_hook = self._hook is not None
-        e = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)
-        grad_uv = e(N, 2) if want_hook else None
-        mag = e(N) if want_hook else None
-        mag_img = e(H, W, 2) if want_hook else None
-        n_aff = e(M, dtype=torch.int32) if want_hook else None
-        h_pc = e(M, 3) if want_hook else None
-        h_feat = e(M, 56) if want_hook else None
-        h_uv = e(M, 2) if want_hook else None
-        h_mag = e(M) if want_hook else None
-        h_ids = e(M, dtype=torch.int32) if want_hook else None
-        h_ntiles = e(M, dtype=torch.int32) if want_hook else None
-        h_depth = e(M) if want_hook else None
-        h_puv = e(M, 2) if want_hook else None
+        grad_uv = mag = mag_img = n_aff = h_pc = h_feat = h_uv = h_mag = h_ids = h_ntiles = h_depth = h_puv = None
+        if want_hook:
+            # twelve arrays, one buffer and one split (the 56-float rows first: the kernel stores them as float4 and the buffer
+            # is aligned); a Python-level tensor op costs 1-2 us, so fewer of them is what shortens this path
+            sizes = (M * 56, M * 3, M * 2, M, M, M * 2, N * 2, N, H * W * 2, M, M, M)
+            parts = torch.empty(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
+            h_feat, h_pc, h_uv, h_mag, h_depth, h_puv = parts[0].view(M, 56), parts[1].view(M, 3), parts[2].view(M, 2), parts[3], parts[4], parts[5].view(M, 2)
+            grad_uv, mag, mag_img = parts[6].view(N, 2), parts[7], parts[8].view(H, W, 2)
+            n_aff, h_ids, h_ntiles = parts[9].view(torch.int32), parts[10].view(torch.int32), parts[11].view(torch.int32)
         ctrl = None
         if self.controller_accumulators is not None:
             ca = self.controller_accumulators
@@ -299,9 +328,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                                     _ptr(h_pc), _ptr(h_feat), _ptr(h_uv), _ptr(h_mag),
                                     C.pointer(ctrl) if ctrl is not None and N > 0 else None,
                                     _ptr(h_ids), _ptr(h_ntiles), _ptr(h_depth), _ptr(h_puv))
-        scene, cam, cfg = self._c_scene(pointcloud, features, mask, obj), self._c_camera(q, t, camera_info, Kmat), self._c_config()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(_native.lib().gs_backward(self._ctx_for(dev), frame.handle, C.byref(scene), C.byref(cam), C.byref(cfg),
                                                     _ptr(grad_image), _ptr(acc_alpha), _ptr(last), int(sh_band),
                                                     C.byref(out), C.c_void_p(stream)), "gs_backward")
