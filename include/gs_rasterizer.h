@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -164,6 +164,7 @@ typedef enum gs_export {
     GS_X_TILE_POINTS_END = 12,          /* (T) i32 */
     GS_X_POINT_DEPTH = 13,              /* (M) f32 = point_in_camera[:,2] */
     GS_X_POINT_IN_CAMERA_MASK = 14,     /* (N) i8 */
+    GS_X_RECORDS = 15,                  /* (M,16) f32: the projected records A|B|C|D of a frame with the projection stage */
     GS_X_COUNT_
 } gs_export;
 
@@ -221,6 +222,15 @@ int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
  * ids_out: device (n_points) i32 or NULL, receives the M in-camera point ids.  M = n_points_in_camera of the frame. */
 int gs_project_shard(gs_ctx* ctx, const gs_scene* shard, const gs_camera* camera, const gs_config* config,
                      float* records_out, int32_t* ids_out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
+
+/* The same stage without the host waiting for M: the kernels are queued and the call returns.  An owner that projects its
+ * shard for W views calls this W times back to back -- the GPU runs the W projections without idling in between -- and only
+ * then asks for the counts: the first gs_frame_get_info / gs_frame_export_count / gs_frame_export / gs_backward_shard on a
+ * frame reads its hand-over (blocking until its kernels have run; an out-of-range point_object_id is reported there).
+ * The records are fetched with gs_frame_export(GS_X_RECORDS), the ids with GS_X_POINT_ID_IN_CAMERA_LIST.  At most 63
+ * frames can be begun and unread at a time per context; further ones wait at once like gs_project_shard. */
+int gs_project_shard_begin(gs_ctx* ctx, const gs_scene* shard, const gs_camera* camera, const gs_config* config,
+                           int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
 
 /* Per-pixel half of the forward from m records (any concatenation of shards' records; ties in the depth sort are
  * broken by position in this array, so concatenating shards in ascending point-id order reproduces gs_forward).

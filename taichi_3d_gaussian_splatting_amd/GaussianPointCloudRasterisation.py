@@ -68,13 +68,25 @@ class _Frame:
     """Owner of a gs_frame ticket: what ctx.save_for_backward keeps in the reference (RAST:998-1021).  Holds the
     context alive (the ticket is meaningless without it) and gives the ticket back when it dies."""
 
-    def __init__(self, context: "_native.Context", handle, device, owned=True):
+    def __init__(self, context: "_native.Context", handle, device, owned=True, lazy=False):
+        """lazy: the frame was only begun (gs_project_shard_begin); its counts are read -- which waits for its kernels -- the
+        first time one of them is asked for."""
         self._context, self._h, self.device, self._owned = context, handle, device, owned
         self.marshalled = None              # (gs_scene, gs_camera, gs_config) of the forward that made the frame
+        if not lazy:
+            self._read_info()
+
+    def _read_info(self):
         info = _native.GsFrameInfo()
-        _native.check(_native.lib().gs_frame_get_info(context.handle, self._h, C.byref(info)), "gs_frame_get_info")
+        _native.check(_native.lib().gs_frame_get_info(self._context.handle, self.handle, C.byref(info)), "gs_frame_get_info")
         self.n_points, self.n_points_in_camera, self.n_keys = info.n_points, info.n_points_in_camera, info.n_keys
         self.n_tiles, self.sort_key_bits, self.stages = info.n_tiles, info.sort_key_bits, info.stages
+
+    def __getattr__(self, name):            # only reached for attributes not set yet: the counts of a lazy frame
+        if name in ("n_points", "n_points_in_camera", "n_keys", "n_tiles", "sort_key_bits", "stages"):
+            self._read_info()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     @property
     def handle(self):

@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
 LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -82,6 +82,7 @@ EXPORTS = {
     "tile_points_end": (12, "int32", ()),
     "point_depth": (13, "float32", ()),
     "point_in_camera_mask": (14, "int8", ()),
+    "records": (15, "float32", (16,)),
 }
 
 # every symbol include/gs_rasterizer.h declares
@@ -89,7 +90,7 @@ SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_for
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
            "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
            "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
-           "gs_project_shard", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
+           "gs_project_shard", "gs_project_shard_begin", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
 
 _lib = None
 
@@ -134,6 +135,7 @@ def lib():
     L.gs_frame_export.argtypes = [_VP, _VP, C.c_int, _VP, _VP]
     L.gs_project_shard.argtypes = [_VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig), _VP, _VP, _I32,
                                    C.POINTER(_VP), _VP]
+    L.gs_project_shard_begin.argtypes = [_VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig), _I32, C.POINTER(_VP), _VP]
     L.gs_forward_projected.argtypes = [_VP, _VP, _I64, C.POINTER(GsCamera), C.POINTER(GsConfig), C.POINTER(GsForwardOut), _I32,
                                        C.POINTER(_VP), _VP]
     L.gs_backward_projected.argtypes = [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]

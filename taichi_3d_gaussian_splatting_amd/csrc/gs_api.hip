@@ -72,6 +72,11 @@ struct Frame {
     int32_t* vals_sorted = nullptr;
     bool live = false;
     uint32_t generation = 0;
+    // gs_project_shard_begin: the hand-over of M (and the object-id check) has not been read yet; slot of the pinned counters
+    // the frame's publish kernel writes, its ticket and the stream to fall back on
+    int pending_slot = -1;
+    int32_t pending_ticket = 0;
+    hipStream_t pending_stream = nullptr;
 };
 
 struct GsProf {
@@ -103,6 +108,7 @@ void gs_prof_end(GsProf* p, int rec, hipStream_t s)
     (void)hipEventRecord(p->recs[rec].b, s);
 }
 
+#define GS_COUNTER_SLOTS 64
 struct gs_ctx {
     int device = 0;
     GsProf prof;
@@ -113,8 +119,9 @@ struct gs_ctx {
     int transient = -1;                 // slot of the frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
     DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums, loss_ws;
-    GsCounters* host_counters = nullptr;   // pinned, device-visible; written by k_scan_tiles_publish
+    GsCounters* host_counters = nullptr;   // pinned, device-visible, GS_COUNTER_SLOTS of them; written by k_scan_tiles_publish
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
+    uint64_t slots_busy = 1ull;            // slot 0 serves the calls that wait at once; the others belong to frames begun and not yet read
     int32_t ticket = 0;                    // sequence number of the last forward
     // dispatch order for the next forward blend: the last backward's tile order (heaviest first).  Only ever a complete
     // permutation of [0, order_hint_T) written by k_tile_order; 0 = none.  A hint only moves work in time.
@@ -145,9 +152,9 @@ extern "C" int gs_create(int32_t device, gs_ctx** out)
     HIP_TRY(hipSetDevice(device));
     gs_ctx* c = new gs_ctx();
     c->device = device;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_counters), sizeof(GsCounters), hipHostMallocMapped | hipHostMallocCoherent);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_counters), sizeof(GsCounters) * GS_COUNTER_SLOTS, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) { delete c; return fail(GS_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
-    std::memset(c->host_counters, 0, sizeof(GsCounters));
+    std::memset(c->host_counters, 0, sizeof(GsCounters) * GS_COUNTER_SLOTS);
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_counters_dev), c->host_counters, 0);
     if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
     e = c->counters.ensure(sizeof(GsCounters), &c->device_bytes);
@@ -246,6 +253,8 @@ static Frame* acquire_frame(gs_ctx* c, int* slot)
 static void drop_frame(gs_ctx* c, Frame* f)
 {
     if (!f || !f->live) return;
+    if (f->pending_slot > 0) c->slots_busy &= ~(1ull << f->pending_slot);      // a late write into a freed slot is harmless: tickets are unique
+    f->pending_slot = -1;
     if (f->bufs) f->bufs->in_use = false;
     f->bufs = nullptr; f->live = false;
     for (size_t i = 0; i < c->frames.size(); ++i) if (c->frames[i] == f && c->transient == (int)i) c->transient = -1;
@@ -291,14 +300,14 @@ static void set_records(GsProjectArgs& pa, const FrameBufs& B, size_t rows)
 // The one device->host hand-over of a frame: M, K, the depth-code range (and the bad-object-id count).  The last
 // prologue kernel writes them into pinned host memory and then the ticket; spinning on it costs a few microseconds
 // where a copy + stream synchronisation left the GPU idle for ~30.
-static int wait_counters(gs_ctx* c, hipStream_t s, int32_t ticket)
+static int wait_counters(gs_ctx* c, hipStream_t s, int32_t ticket, int slot = 0)
 {
     static const bool wait_on_stream = []{ const char* e = getenv("GS_COUNTERS_WAIT"); return e && std::strcmp(e, "stream") == 0; }();
     if (wait_on_stream) {                   // diagnostic alternative: block in the runtime instead of spinning
         HIP_TRY(hipStreamSynchronize(s));
         return GS_OK;
     }
-    volatile GsCounters* hc = c->host_counters;
+    volatile GsCounters* hc = c->host_counters + slot;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spin = 0; hc->reserved != ticket; ++spin) {
         if ((spin & 0xfffu) == 0xfffu) {
@@ -353,8 +362,9 @@ static int check_forward_out(const gs_forward_out* out, const gs_config* cfg, in
 
 // ---- per-point half: filter, compaction, projection (+ tile counts, scan, publication) ----------------------------
 // On success the frame's buffers hold mask / ids / cam_index / records / box / ntiles and M, K, max_code are known.
+// defer: do not wait for the hand-over -- the frame keeps a counter slot and whoever needs M first reads it (resolve_pending).
 static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg, int T,
-                             hipStream_t s, GsProjectArgs* pa_out, int* M_out, uint32_t* K_out, int* max_code_out)
+                             hipStream_t s, GsProjectArgs* pa_out, int* M_out, uint32_t* K_out, int* max_code_out, bool defer = false)
 {
     FrameBufs& B = *f->bufs;
     const int64_t N = sc->n_points;
@@ -384,10 +394,21 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
-    pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
+    int slot = 0;
+    if (defer && N > 0) {
+        const uint64_t free_slots = ~c->slots_busy;
+        if (free_slots != 0ull) { slot = __builtin_ctzll(free_slots); c->slots_busy |= 1ull << slot; }     // none left: wait at once
+    }
+    pa.host_mirror = c->host_counters_dev + slot; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_project(pa, s);
     HIP_TRY_F(hipGetLastError());
+    *pa_out = pa;
+    if (slot > 0) {
+        f->pending_slot = slot; f->pending_ticket = pa.ticket; f->pending_stream = s;
+        *M_out = 0; *K_out = 0u; *max_code_out = 0;
+        return GS_OK;
+    }
     if (N > 0) {
         const int rc = wait_counters(c, s, pa.ticket);
         if (rc != GS_OK) { drop_frame(c, f); return rc; }
@@ -523,6 +544,50 @@ extern "C" int gs_project_shard(gs_ctx* c, const gs_scene* sc, const gs_camera* 
     return GS_OK;
 }
 
+// Reads the hand-over of a frame begun with gs_project_shard_begin (mutex held): M, K and the object-id verdict.
+static int resolve_pending(gs_ctx* c, Frame* f)
+{
+    if (!f || f->pending_slot <= 0) return GS_OK;
+    const int slot = f->pending_slot;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = wait_counters(c, f->pending_stream, f->pending_ticket, slot);
+    const GsCounters hc = c->host_counters[slot];
+    c->slots_busy &= ~(1ull << slot);
+    f->pending_slot = -1;
+    if (rc != GS_OK) { drop_frame(c, f); return rc; }
+    if (hc.bad_object_ids != 0) {
+        drop_frame(c, f);
+        return fail(GS_ERR_INVALID_ARGUMENT, "point_object_id holds " + std::to_string(hc.bad_object_ids) + " value(s) outside [0, n_objects) on valid rows");
+    }
+    f->info.n_points_in_camera = hc.M;
+    f->info.n_keys = hc.K;
+    return GS_OK;
+}
+
+extern "C" int gs_project_shard_begin(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg,
+                                      int32_t keep, gs_frame** frame_out, gs_stream stream_)
+{
+    if (!c || !sc || !cam || !cfg || !frame_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_project_shard_begin: NULL argument");
+    int tiles_x = 0, tiles_y = 0, rc;
+    if ((rc = check_geometry(cam, cfg, "gs_project_shard_begin", &tiles_x, &tiles_y)) != GS_OK) return rc;
+    if ((rc = check_scene(sc, cam, "gs_project_shard_begin")) != GS_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, s));
+    if (c->transient >= 0) drop_frame(c, c->frames[c->transient]);
+    int slot = -1;
+    Frame* f = acquire_frame(c, &slot);
+    f->bufs = acquire_bufs(c);
+    f->info = gs_frame_info{};
+    const int T = tiles_x * tiles_y;
+    GsProjectArgs pa{};
+    int M = 0, max_code = 0; uint32_t K = 0;
+    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code, true)) != GS_OK) return rc;
+    finish_frame(c, f, slot, sc->n_points, M, K, T, cam->camera_height, cam->camera_width, keep, GS_STAGE_PROJECT, frame_out);
+    return GS_OK;
+}
+
 extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, const gs_camera* cam, const gs_config* cfg,
                                     const gs_forward_out* out, int32_t keep, gs_frame** frame_out, gs_stream stream_)
 {
@@ -574,8 +639,9 @@ extern "C" int gs_frame_get_info(gs_ctx* c, const gs_frame* h, gs_frame_info* in
 {
     if (!c || !info) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_get_info: NULL argument");
     std::lock_guard<std::mutex> lock(c->mu);
-    const Frame* f = resolve(c, h);
+    Frame* f = resolve(c, h);
     if (!f) return fail(GS_ERR_STATE, "gs_frame_get_info: not a live frame of this context");
+    if (const int rc = resolve_pending(c, f)) return rc;
     *info = f->info;
     return GS_OK;
 }
@@ -592,6 +658,7 @@ static int64_t export_count(const Frame* f, gs_export what)
     case GS_X_POINT_UV: return 2 * M;
     case GS_X_POINT_IN_CAMERA: case GS_X_POINT_COLOR: return 3 * M;
     case GS_X_POINT_UV_CONIC_AND_RESCALE: return 4 * M;
+    case GS_X_RECORDS: return proj ? 16 * M : -1;
     case GS_X_SORT_KEY: case GS_X_POINT_OFFSET_WITH_SORT_KEY: return rast ? K : -1;
     case GS_X_TILE_POINTS_START: case GS_X_TILE_POINTS_END: return rast ? T : -1;
     default: return -1;
@@ -602,7 +669,8 @@ extern "C" int64_t gs_frame_export_count(gs_ctx* c, const gs_frame* h, gs_export
 {
     if (!c) return -1;
     std::lock_guard<std::mutex> lock(c->mu);
-    const Frame* f = resolve(c, h);
+    Frame* f = resolve(c, h);
+    if (f && resolve_pending(c, f) != GS_OK) return -1;
     return f ? export_count(f, what) : -1;
 }
 
@@ -619,13 +687,20 @@ extern "C" int gs_frame_export(gs_ctx* c, const gs_frame* h, gs_export what, voi
     if (!dst) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: dst is NULL");
     if (what < 0 || what >= GS_X_COUNT_) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_export: unknown export id");
     std::lock_guard<std::mutex> lock(c->mu);
-    const Frame* f = resolve(c, h);
+    Frame* f = resolve(c, h);
     if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_export: not a live frame of this context");
+    if (const int rc = resolve_pending(c, f)) return rc;
     if (export_count(f, what) < 0) return fail(GS_ERR_STATE, "gs_frame_export: this frame does not hold that stage");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     HIP_TRY(enter_stream(c, s));
     const FrameBufs& B = *f->bufs;
+    if (what == GS_X_RECORDS) {                  // the (M,16) rows as they are: what the owner of a shard sends to the renderers
+        static_assert(GS_RS == 4, "records are exported as (M,16) rows");
+        if (f->info.n_points_in_camera > 0)
+            HIP_TRY(hipMemcpyAsync(dst, B.rec.p, (size_t)f->info.n_points_in_camera * 64, hipMemcpyDeviceToDevice, s));
+        return GS_OK;
+    }
     GsExportArgs a{};
     a.what = (int)what; a.N = f->info.n_points; a.M = (int)f->info.n_points_in_camera; a.K = (uint32_t)f->info.n_keys;
     a.T = f->info.n_tiles; a.depth_bits = f->depth_bits; a.key64 = f->key64;
@@ -803,6 +878,7 @@ extern "C" int gs_backward_shard(gs_ctx* c, gs_frame* h, const gs_scene* sc, con
     std::lock_guard<std::mutex> lock(c->mu);
     Frame* f = resolve(c, h);
     if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_backward_shard: not a live frame of this context");
+    if (const int rp = resolve_pending(c, f)) return rp;
     if (!f->info.kept_for_backward) return fail(GS_ERR_STATE, "gs_backward_shard: frame was not kept for backward");
     if (!(f->info.stages & GS_STAGE_PROJECT)) return fail(GS_ERR_STATE, "gs_backward_shard: frame holds no projection stage");
     if (f->info.n_points_in_camera > 0 && !splat_sums) return fail(GS_ERR_INVALID_ARGUMENT, "gs_backward_shard: splat_sums is NULL");

@@ -180,8 +180,7 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         if (!((mq[qi] >> j) & 1ull)) continue;                // wave-uniform
                         GS_STAT(10, 1);
                         // lane predicates as wave-uniform SGPR masks (see k_blend_fwd)
-                        const unsigned long long inr_m = gs_ballot((lo + j) < Q[qi].last);   // RAST:609-610
-                        if (inr_m == 0ull) continue;
+                        const unsigned long long inr_m = gs_ballot((lo + j) < Q[qi].last);   // RAST:609-610 (never empty here: the batch cull saw a pixel in range)
                         GS_STAT(11, 1);
                         // grad_point_probability_density_from_conic_and_rescale, UTIL:331-348.  Fast form (fused multiply-adds,
                         // hardware v_exp_f32): alpha is within 2e-6 (relative) of the reference operation sequence, so unless
@@ -192,13 +191,15 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         // exp(-0.5 * q) = 2^(q * (-0.5 * log2 e)): one multiply instead of two
                         float g = __builtin_amdgcn_exp2f(__builtin_fmaf(dx, cix, dy * ciy) * -0.72134752044448170f) * b4.y;
                         float prod_alpha = g * apt;
-                        if ((gs_ballot(fabsf(prod_alpha - GS_ALPHA_EPS) < 4.0e-8f) & inr_m) != 0ull) {
+                        // RAST:634 against both edges of the band: where the two votes agree no lane is inside it (two compares, no subtraction)
+                        unsigned long long use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS + 4.0e-8f) & inr_m;
+                        if (use_m != (gs_ballot(prod_alpha >= GS_ALPHA_EPS - 4.0e-8f) & inr_m)) {
                             const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
                             g = gs_exp_blend(-0.5f * (dx * sx + dy * sy)) * b4.y;
                             prod_alpha = g * apt;
+                            use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;
                             GS_STAT(14, 1);
                         }
-                        const unsigned long long use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;   // RAST:634
                         n_use += __popcll(use_m);
                         GS_STAT(12, __popcll(use_m)); GS_STAT(15, use_m != 0ull ? 1 : 0);
                         if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
             // unconditionally and the compiler keeps the two alpha chains in one block, where it interleaves them
             GS_FWD_STEP(alpha1, a41, b41, c41, j1, two ? alive : 0ull)
 #undef GS_FWD_STEP
-            if (alive == 0ull) mask = 0ull;
+            if (alive == 0ull) break;
         }
         __builtin_amdgcn_wave_barrier();
     }

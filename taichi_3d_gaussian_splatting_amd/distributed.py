@@ -159,10 +159,15 @@ def gaussian_parallel_step(backend, grad_of_image, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     recs, handles = [], []
-    for v in range(world):
-        r, h = backend.project(v)
-        recs.append(r)
-        handles.append(h)
+    if hasattr(backend, "project_all"):          # queue all views' projections first, read their counts afterwards: one wait, not W
+        for r, h in backend.project_all(range(world)):
+            recs.append(r)
+            handles.append(h)
+    else:
+        for v in range(world):
+            r, h = backend.project(v)
+            recs.append(r)
+            handles.append(h)
     send_rows = [int(r.shape[0]) for r in recs]
     counts = torch.tensor(send_rows, dtype=torch.int64, device=recs[0].device)
     table = [torch.empty_like(counts) for _ in range(world)]
@@ -208,6 +213,10 @@ class HipStageBackend:
     def project(self, view):
         rec, _ids, frame = self.st.project_shard(self._input_for(view))
         return rec, (view, frame)
+
+    def project_all(self, views):
+        frames = [(v, self.st.project_shard_begin(self._input_for(v))) for v in views]
+        return [(self.st.project_shard_finish(f, want_ids=False)[0], (v, f)) for v, f in frames]
 
     def render(self, records):
         outs, frame = self.st.forward_projected(records.contiguous(), self.inp.camera_info)

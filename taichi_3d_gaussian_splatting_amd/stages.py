@@ -68,6 +68,31 @@ class StagedRasteriser:
         M = frame.n_points_in_camera
         return records[:M], ids[:M], frame
 
+    def project_shard_begin(self, inp: "_Rast.GaussianPointCloudRasterisationInput", keep: bool = True) -> _Frame:
+        """Queues the same stage and returns at once (gs_project_shard_begin): an owner projecting its shard for several views
+        begins them all, so that the GPU runs them back to back, and fetches each result with project_shard_finish()."""
+        m = self.module
+        pc, ft = inp.point_cloud, inp.point_cloud_features
+        Kmat = m._validate(pc, ft, inp.point_invalid_mask, inp.point_object_id, inp.q_pointcloud_camera,
+                           inp.t_pointcloud_camera, inp.camera_info)
+        dev = pc.device
+        context = m._context_for(dev)
+        frame_h = C.c_void_p()
+        scene = m._c_scene(pc, ft, inp.point_invalid_mask, inp.point_object_id)
+        cam = m._c_camera(inp.q_pointcloud_camera, inp.t_pointcloud_camera, inp.camera_info, Kmat)
+        cfg = m._c_config()
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs_project_shard_begin(
+                context.handle, C.byref(scene), C.byref(cam), C.byref(cfg), 1 if keep else 0,
+                C.byref(frame_h), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gs_project_shard_begin")
+        frame = _Frame(context, frame_h, dev, owned=keep, lazy=True)
+        frame._keepalive = (Kmat, inp.q_pointcloud_camera, inp.t_pointcloud_camera)      # read by kernels that may not have run yet
+        return frame
+
+    def project_shard_finish(self, frame: _Frame, want_ids: bool = True):
+        """(records (M,16) f32, ids (M) i32 ascending or None) of a frame begun with project_shard_begin; waits for its kernels."""
+        return frame.export("records"), (frame.export("point_id_in_camera_list") if want_ids else None)
+
     # -- per-pixel half, forward ------------------------------------------------------------------------------------
     def forward_projected(self, records: torch.Tensor, camera_info, keep: bool = True):
         """records: (M,16) f32 contiguous, any concatenation of shards' records.  Returns (RasterOutputs, frame)."""

@@ -172,6 +172,46 @@ def test_out_of_range_object_ids_are_reported_not_dereferenced(P):
     assert P.rel_err(image.cpu().numpy(), f.rasterized_image) < P.IMAGE_TOL
 
 
+def test_projections_begun_back_to_back_equal_the_waiting_call(P):
+    """gs_project_shard_begin queues the per-point half and returns; the counts are read when first asked for.  Eight views
+    begun back to back (what an owner does in the Gaussian-parallel scheme) give the records, ids and -- through gs_backward_shard --
+    the gradients of eight gs_project_shard calls, bit for bit; a bad object id surfaces when the frame is first read; frames
+    dropped unread and more begun frames than counter slots are harmless."""
+    s = synth(7000, 256, 160, 0.06, sh_deg=3, seed=58)
+    s.point_invalid_mask[np.random.default_rng(3).random(7000) < 0.05] = 1
+    st = StagedRasteriser()
+    poses = [view_pose(v, 8) for v in range(8)]
+    # fresh tensors for every call: the projection normalises the quaternions in place (RAST:264-266) and doing that twice is
+    # not bitwise idempotent, so like is compared with like
+    fresh = lambda: [P.make_input(s, q, t, 3, requires_grad=False) for q, t in poses]
+    inputs, inputs_b = fresh(), fresh()
+    want = [st.project_shard(i) for i in inputs]                                   # (records, ids, frame), waiting each time
+    frames = [st.project_shard_begin(i) for i in inputs_b]
+    got = [st.project_shard_finish(f) for f in frames]
+    rng = np.random.default_rng(4)
+    for (rec_w, ids_w, fr_w), (rec_g, ids_g), fr_g, inp, inp_b in zip(want, got, frames, inputs, inputs_b):
+        assert fr_g.n_points_in_camera == fr_w.n_points_in_camera == rec_g.shape[0] > 0
+        assert np.array_equal(_bits(rec_g), _bits(rec_w)) and np.array_equal(ids_g.cpu().numpy(), ids_w.cpu().numpy())
+        sums = torch.tensor(rng.standard_normal((rec_g.shape[0], 12)).astype(np.float32), device=rec_g.device)
+        sums[:, 10] = torch.tensor(rng.integers(0, 5, rec_g.shape[0]).astype(np.int32), device=rec_g.device).view(torch.float32)
+        a, b = st.backward_shard(fr_w, inp, sums), st.backward_shard(fr_g, inp_b, sums)
+        assert np.array_equal(_bits(a.grad_pointcloud), _bits(b.grad_pointcloud))
+        assert np.array_equal(_bits(a.grad_pointcloud_features), _bits(b.grad_pointcloud_features))
+    # more frames begun than the context has counter slots (63), most of them never read: the extra ones simply wait at once
+    many = [st.project_shard_begin(inputs[k % 8]) for k in range(80)]
+    assert many[70].n_points_in_camera == want[70 % 8][2].n_points_in_camera
+    assert many[3].n_points_in_camera == want[3][2].n_points_in_camera
+    del many
+    # an out-of-range object id is reported when the frame is first read, and the context stays usable
+    bad = synth(1000, 64, 64, 0.1, seed=55)
+    bad.point_object_id[10] = 7
+    fr = st.project_shard_begin(P.make_input(bad, *view_pose(), 3, requires_grad=False))
+    with pytest.raises(RuntimeError, match="point_object_id"):
+        fr.n_points_in_camera
+    rec, ids = st.project_shard_finish(st.project_shard_begin(fresh()[0]))
+    assert np.array_equal(_bits(rec), _bits(want[0][0]))
+
+
 def _valid_ids(s):
     import copy
     c = copy.copy(s)
