@@ -61,7 +61,8 @@ struct GsCounters {
 // ---- device math -------------------------------------------------------------
 __device__ __forceinline__ float gs_expf(float x)
 {
-    x = __builtin_amdgcn_fmed3f(x, -86.0f, 88.0f);   // clamp (one v_med3_f32); same value as the two compares of the oracle
+    x = x < -86.0f ? -86.0f : x;                     // the oracle's two compares, so that a NaN parameter stays a NaN as in the reference
+    x = x > 88.0f ? 88.0f : x;                       // (v_med3_f32 / v_min / v_max would return the finite operand)
     float fx = x * 1.44269504088896341f;
     float n = (fx + 12582912.0f) - 12582912.0f;      // round to nearest even
     float r = __builtin_fmaf(n, -0.693359375f, x);
@@ -85,7 +86,8 @@ __device__ __forceinline__ float gs_expf(float x)
 // added to the exponent field (v_lshl_add_u32).  Within 3e-7 of exp for x in [-10, 0].
 __device__ __forceinline__ float gs_exp_blend(float x)
 {
-    x = __builtin_amdgcn_fmed3f(x, -86.0f, 88.0f);
+    x = __builtin_amdgcn_fmed3f(x, -86.0f, 88.0f);   // (a NaN exponent -- NaN position, rotation or scale -- becomes -86: such a splat has no
+                                                     // defined tile box in the reference either; NaN colour and opacity do propagate)
     const float L = 1.44269504088896341f;
     const float t = x * L;
     const float m = t + 12582912.0f;

@@ -132,6 +132,13 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     int tile_last = qlast[0];
 #pragma unroll
     for (int qi = 1; qi < NQ; ++qi) tile_last = max(tile_last, qlast[qi]);
+    bool pixels_finite;                          // every pixel gradient and final T of this wave is a finite number
+    {
+        float t = 0.0f;
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) t += ((Q[qi].gr + Q[qi].gg) + Q[qi].gb) + Q[qi].T;
+        pixels_finite = gs_ballot(!(t - t == 0.0f)) == 0ull;
+    }
     float pxq[NQ], pyq[NQ];                      // pixel centres of this lane in its NQ quadrants
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) { pxq[qi] = rx0[qi] + (float)lx; pyq[qi] = ry0[qi] + (float)ly; }
@@ -157,6 +164,14 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                 U |= mq[qi];
             }
             GS_STAT(8, 1);
+            // `clean`: nothing that enters the arithmetic below is NaN or infinite (the batch's records, the running sums W; this
+            // wave's pixel gradients, checked once).  Only then may a lane that takes nothing from a splat run the same instructions on
+            // alpha = 0 (0 * NaN would not be 0); otherwise the exec-masked form is used for the whole batch.
+            float fsum = ((A.x + A.y) + (A.z + A.w)) + ((B.x + B.y) + B.z) + ((C.x + C.y) + C.z);
+            fsum = valid ? fsum : 0.0f;
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) fsum += Q[qi].W;              // (a NaN colour met in an earlier batch lives on in W)
+            const bool clean = pixels_finite && gs_ballot(!(fsum - fsum == 0.0f)) == 0ull;
             if (U) {
                 uint32_t slot = 0;
                 if ((U >> lane) & 1ull) {                                     // pre-sort slot of this (point, tile) pair
@@ -202,7 +217,34 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         }
                         n_use += __popcll(use_m);
                         GS_STAT(12, __popcll(use_m)); GS_STAT(15, use_m != 0ull ? 1 : 0);
-                        if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing
+                        if (qi == 0 && clean) {                               // wave-uniform
+                            // The first quadrant WRITES the ten sums, and all 64 lanes run the block: a lane that does not contribute
+                            // computes on alpha = 0 and g = 0 (two selects), which makes each of its terms an exact zero and leaves its
+                            // T and W as they were.  Clearing ten registers first and masking exec around the block (scalar
+                            // instructions and a branch, in a kernel whose waves mostly wait on each other's latencies) costs more:
+                            // 0.242 -> 0.228 ms.  Contributing lanes execute exactly the masked form's operations.
+#pragma clang fp contract(fast)
+                            const bool use = __builtin_amdgcn_inverse_ballot_w64(use_m);
+                            const float alpha = use ? __int_as_float(min(__float_as_int(prod_alpha), __float_as_int(GS_ALPHA_MAX))) : 0.0f;
+                            const float gg = use ? g : 0.0f;
+                            const float one_m = 1.0f - alpha;
+                            const float inv = __builtin_amdgcn_rcpf(one_m);
+                            const float Tn = Q[qi].T * inv;
+                            const float cg = c4.x * Q[qi].gr + c4.y * Q[qi].gg + c4.z * Q[qi].gb;
+                            const float ag = Tn * cg - inv * Q[qi].W;
+                            const float d_rgb = alpha * Tn;
+                            const float agg = ag * gg;
+                            const float vs0 = agg * cix, vs1 = agg * ciy;
+                            v[0] = vs0; v[1] = vs1;
+                            v[2] = vs0 * cix; v[3] = vs0 * ciy; v[4] = vs1 * ciy;
+                            v[5] = d_rgb * Q[qi].gr; v[6] = d_rgb * Q[qi].gg; v[7] = d_rgb * Q[qi].gb;
+                            v[8] = agg;
+                            v[9] = __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);
+                            Q[qi].T = Tn;
+                            Q[qi].W = __builtin_fmaf(cg, d_rgb, Q[qi].W);
+                            Q[qi].tot0 = __builtin_fmaf(fabsf(vs0), apt, Q[qi].tot0);
+                            Q[qi].tot1 = __builtin_fmaf(fabsf(vs1), apt, Q[qi].tot1);
+                        } else if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                // exec-masked: idle lanes add nothing
                             // float outputs only from here on: let the compiler fuse multiply-adds
 #pragma clang fp contract(fast)
                             // min(prod_alpha, 0.99), RAST:636: both positive, so the integer minimum of the bit patterns (no canonicalise)
@@ -267,10 +309,15 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     if (lane == 0 && blockIdx.x < 65536) { gs_stats_wave_times[2 * blockIdx.x] = gs_t0; gs_stats_wave_times[2 * blockIdx.x + 1] = wall_clock64(); }
 #endif
     if (mag_image) {                                                            // RAST:700-704
+        // pixel coordinates derived afresh (the asm hides that they equal the prologue's): five registers would otherwise stay
+        // live across the whole walk, and the kernel sits exactly at the 96-VGPR boundary of five waves per SIMD
+        int lane_e = threadIdx.x;
+        asm volatile("" : "+v"(lane_e));
+        const int lx_e = lane_e & 7, ly_e = lane_e >> 3;
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             const int q = grp * NQ + qi;
-            const int pu = tile_u * 16 + (q & 1) * 8 + lx, pv = tile_v * 16 + (q >> 1) * 8 + ly;
+            const int pu = tile_u * 16 + (q & 1) * 8 + lx_e, pv = tile_v * 16 + (q >> 1) * 8 + ly_e;
             if (pu >= W || pv >= H) continue;
             const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
             mag_image[2 * o] = Q[qi].tot0; mag_image[2 * o + 1] = Q[qi].tot1;

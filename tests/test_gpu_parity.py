@@ -175,6 +175,37 @@ def test_dispatch_order_hint_from_an_earlier_frame_changes_nothing(P):
             assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
 
 
+def test_not_a_number_stays_where_the_reference_puts_it(P):
+    """The backward blend lets lanes that take nothing from a splat run the first quadrant's arithmetic on alpha = 0 -- only
+    while everything entering it is finite (k_backward.hip: `clean`).  With a NaN colour on one splat, and with a NaN in the
+    incoming image gradient, the exec-masked form must take over: NaN then reaches exactly the gradient elements it reaches in
+    the reference algorithm (the oracle), and every other element keeps its value."""
+    s = synth(3000, 128, 96, 0.08, sh_deg=3, seed=23)
+    q, t = view_pose()
+    f0, _ = P.run_oracle(s, q, t)
+    cnt = P.oracle.backward(f0, np.ones((96, 128, 3), np.float32), 3)["num_affected_pixels"]
+    victim = int(f0.point_id_in_camera_list[int(np.argmax(cnt))])               # a splat that certainly contributes somewhere
+    for case in ("nan_colour", "nan_gradient"):
+        sc = synth(3000, 128, 96, 0.08, sh_deg=3, seed=23)
+        g = (np.random.default_rng(24).standard_normal((96, 128, 3)) * 0.1).astype(np.float32)
+        if case == "nan_colour":
+            sc.point_cloud_features[victim, 8] = np.nan                           # red DC coefficient
+        else:
+            g[40, 50, 1] = np.nan
+        module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+        inp = P.make_input(sc, q, t, 3)
+        image = module(inp)[0]
+        image.backward(torch.tensor(g, device=image.device))
+        f, _ = P.run_oracle(sc, q, t)
+        b = P.oracle.backward(f, g, 3)
+        for got, ref, name in ((inp.point_cloud.grad.cpu().numpy(), b["grad_pointcloud"], "xyz"),
+                               (inp.point_cloud_features.grad.cpu().numpy(), b["grad_pointcloud_features"], "features")):
+            assert np.isnan(ref).any(), (case, name)                              # the case does exercise NaN
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (case, name, int(np.isnan(got).sum()), int(np.isnan(ref).sum()))
+            ok = ~np.isnan(ref)
+            assert np.abs(got[ok] - ref[ok]).max() <= 1e-4 * np.abs(ref[ok]).max(), (case, name)
+
+
 def test_argument_errors(P):
     s = synth(16, 64, 64, 0.1)
     q, t = view_pose()
