@@ -170,12 +170,9 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
     if ((int)threadIdx.x < cnt) {
         int pid = sIds[threadIdx.x];
         float4* row4 = reinterpret_cast<float4*>(feat + (size_t)GS_NFEAT * pid);
-        // Only the first 32 bytes of the row (rotation, scales, opacity) are loaded here; the 48 colour coefficients are fetched
-        // one channel at a time where they are consumed.  With the whole 56-float row in registers the kernel needed 114 VGPRs
-        // (4 waves per SIMD, and the grid is less than two such rounds deep).
-        float row[8];
+        float row[GS_NFEAT];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < GS_NFEAT / 4; ++k) {
             float4 v = row4[k];
             row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
         }
@@ -254,12 +251,7 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
         float col[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float f[16];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 v = row4[2 + 4 * ch + k];
-                f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
-            }
+            const float* f = row + 8 + 16 * ch;
             float acc = f[0] * sh[0];
 #pragma unroll
             for (int k = 1; k < 16; ++k) acc = acc + f[k] * sh[k];
