@@ -97,16 +97,29 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
         if (mask == 0ull) continue;
         evals += __popcll(mask);
         sRec[wave][lane][0] = A; sRec[wave][lane][1] = B; sRec[wave][lane][2] = C;
+        // The loop below takes the survivors two at a time.  An odd count is made even with a filler: the record of some lane
+        // that did not survive is overwritten with a splat of opacity 0 (alpha = 0 fails the 1/255 test for every pixel), so the
+        // loop needs no "is there a second one" logic.  (64 survivors are even already; an odd count leaves a lane free.)
+        if (__popcll(mask) & 1) {
+            const int jz = __builtin_ctzll(~mask);
+            if (lane == jz) {
+                sRec[wave][lane][0] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                sRec[wave][lane][1] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+                sRec[wave][lane][2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            mask |= 1ull << jz;
+        }
         __builtin_amdgcn_wave_barrier();
         // Two splats per trip: their alphas are independent (two dependency chains to interleave: a quadrant's walk is
         // otherwise one long chain of dependent instructions, and the end of the launch runs with few waves per SIMD
         // to hide it behind), the two blend steps then run in list order.  Same operations per splat as one at a time.
+        int lj = -1;                                // batch position of this pixel's latest contributor, if any
         while (mask) {
+            // (s_bitset0_b64 clears the bit in one scalar instruction; `mask &= mask - 1` is a 64-bit subtract and an and: three)
             const int j0 = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const bool two = mask != 0ull;                                      // wave-uniform
-            const int j1 = two ? __builtin_ctzll(mask) : j0;
-            mask &= mask - 1ull;                                                // 0 stays 0
+            asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(j0));
+            const int j1 = __builtin_ctzll(mask);                               // (an even number of bits: see the filler above)
+            asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(j1));
             const float4 a40 = sRec[wave][j0][0], b40 = sRec[wave][j0][1], c40 = sRec[wave][j0][2];
             const float4 a41 = sRec[wave][j1][0], b41 = sRec[wave][j1][1], c41 = sRec[wave][j1][2];
             // get_point_probability_density_from_conic_and_rescale, UTIL:275-284 (same op order)
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
                 use_m &= ~sat_m;                                                                                                 \
                 GS_STAT(3, __popcll(use_m)); GS_STAT(5, __popcll(alive));                                                        \
                 if (__builtin_amdgcn_inverse_ballot_w64(use_m)) {                                                                \
-                    last = base + (J) + 1;                                                /* RAST:461 */                          \
+                    lj = (J);                                  /* RAST:461: position in the batch; the base is added once per batch */ \
                     /* alpha and T (and with them every index the forward returns) follow the reference operation sequence   */ \
                     /* bit for bit; the weighted sums use one shared weight and fused multiply-adds (float outputs, 1e-4 bar) */ \
                     const float w = alpha * T_i;                                                                                 \
@@ -142,10 +155,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
             GS_FWD_STEP(alpha0, a40, b40, c40, j0, alive)
             // no branch around the second step (a missing second splat just has no live lanes): its alpha is then needed
             // unconditionally and the compiler keeps the two alpha chains in one block, where it interleaves them
-            GS_FWD_STEP(alpha1, a41, b41, c41, j1, two ? alive : 0ull)
+            GS_FWD_STEP(alpha1, a41, b41, c41, j1, alive)
 #undef GS_FWD_STEP
             if (alive == 0ull) break;
         }
+        last = lj >= 0 ? base + lj + 1 : last;
         __builtin_amdgcn_wave_barrier();
     }
 #ifdef GS_STATS
