@@ -72,6 +72,22 @@ float gso_exp_blend(float x)
     return a.f;
 }
 
+/* the exp of the blend loops as gso_config.blend_exp selects it (gs_oracle.h) */
+static inline float blend_exp_select(float x, int which)
+{
+    if (which == GSO_EXP_LIBM) return expf(x);
+    if (which == GSO_EXP_FAST2) { float t = x * 1.44269504088896341f; return exp2f(t); }
+    if (which == GSO_EXP_ULP2) {                 /* FAST2 moved by -2..+2 ulp, chosen by a hash of the argument's bits */
+        float t = x * 1.44269504088896341f;
+        union { float f; uint32_t u; int32_t i; } a, r;
+        a.f = x; r.f = exp2f(t);
+        uint32_t h = a.u * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        if (r.f > 1e-30f) r.i += (int32_t)(h % 5u) - 2;
+        return r.f;
+    }
+    return gso_exp_blend(x);
+}
+
 /* UTIL:351-353 ti_sigmoid */
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + gso_expf(-x)); }
 
@@ -507,6 +523,8 @@ static void raster_stage(gso_frame* f, const gso_config* cfg)
     f->pixel_offset_of_last_effective_point = (int32_t*)zalloc(sizeof(int32_t) * P);
     f->pixel_valid_point_count = (int32_t*)zalloc(sizeof(int32_t) * P);
     const int rgb_only = cfg->rgb_only;
+    const int which_exp = cfg->blend_exp;
+    f->blend_exp = which_exp;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t tile_id = 0; tile_id < f->T; ++tile_id) {
         int32_t tile_u = tile_id % f->tiles_x, tile_v = tile_id / f->tiles_x;
@@ -525,7 +543,7 @@ static void raster_stage(gso_frame* f, const gso_config* cfg)
                 /* UTIL:275-284 */
                 float dx = px - f->point_uv[2 * (size_t)p], dy = py - f->point_uv[2 * (size_t)p + 1];
                 float exponent = -0.5f * (dx * dx * cn[0] + dy * dy * cn[2]) - dx * dy * cn[1];
-                float gaussian_alpha = gso_exp_blend(exponent) * cn[3];
+                float gaussian_alpha = blend_exp_select(exponent, which_exp) * cn[3];
                 float alpha = gaussian_alpha * f->point_alpha_after_activation[p];
                 if (alpha < GSO_ALPHA_EPS) continue;            /* RAST:451 */
                 alpha = min_f(alpha, 0.99f);                     /* RAST:453 */
@@ -718,9 +736,10 @@ int gso_backward(const gso_frame* f, const float* pc, const float* feat, const i
 /* loop 1 (RAST:531-705) into the reference's accumulators; doubles stand in for ti.atomic_add (RAST:674-696) */
 typedef struct { double *a_uv, *a_cov, *a_col, *a_alpha, *a_mag, *a_abs; int64_t* a_cnt; } gso_acc;
 
-static void backward_loop1(const gso_frame* f, const float* grad_image, float* mag_img, gso_acc acc)
+static void backward_loop1(const gso_frame* f, const float* grad_image, float* mag_img, gso_acc acc, int strict_dpdcov)
 {
     const int32_t W = f->W;
+    const int which_exp = f->blend_exp;                          /* the exp the forward of this frame used */
     double *a_uv = acc.a_uv, *a_cov = acc.a_cov, *a_col = acc.a_col, *a_alpha = acc.a_alpha, *a_mag = acc.a_mag, *a_abs = acc.a_abs;
     int64_t* a_cnt = acc.a_cnt;
     /* ---- loop 1, RAST:531-705; tiles in parallel, sums via atomic double adds ---- */
@@ -750,12 +769,16 @@ static void backward_loop1(const gso_frame* f, const float* grad_image, float* m
                 float cix = a * dx + b * dy, ciy = b * dx + c * dy;
                 float quad = dx * cix + dy * ciy;
                 float exponent = -0.5f * quad;
-                float gaussian_alpha = gso_exp_blend(exponent) * cn[3];
+                float gaussian_alpha = blend_exp_select(exponent, which_exp) * cn[3];
                 float dpm0 = gaussian_alpha * cix, dpm1 = gaussian_alpha * ciy;
+                /* UTIL:343-345: 0.5 p (Sigma^-1 (d d^T) Sigma^-1), two 2x2 products in f32 */
                 float oxx = dx * dx, oxy = dx * dy, oyx = dy * dx, oyy = dy * dy;
                 float io00 = a * oxx + b * oyx, io01 = a * oxy + b * oyy;
                 float io10 = b * oxx + c * oyx, io11 = b * oxy + c * oyy;
                 float m00 = io00 * a + io01 * b, m01 = io00 * b + io01 * c, m11 = io10 * b + io11 * c;
+                if (!strict_dpdcov) {        /* diagnostic only (gso_config.bwd_strict_dpdcov = 0): the same matrix as v v^T, v = Sigma^-1 d */
+                    m00 = cix * cix; m01 = cix * ciy; m11 = ciy * ciy;
+                }
                 float hp = 0.5f * gaussian_alpha;
                 float dpc00 = hp * m00, dpc01 = hp * m01, dpc11 = hp * m11;
                 float apt = f->point_alpha_after_activation[p];
@@ -948,7 +971,7 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
     (void)q_pc;
     const int64_t M = f->M;
     gso_acc acc = acc_alloc(M, summed_pc || summed_feat);
-    backward_loop1(f, grad_image, mag_img, acc);
+    backward_loop1(f, grad_image, mag_img, acc, cfg->bwd_strict_dpdcov);
     float* sums = (float*)zalloc(sizeof(float) * 12 * (size_t)M);
     pack_sums(M, acc, sums);
     backward_loop2(f, pc, feat, obj, t_pc, Km, sums, acc.a_abs, sh_band, cfg, g_pc, g_feat, g_uv, mag, n_affected,
@@ -962,7 +985,7 @@ int gso_backward_ex(const gso_frame* f, const float* pc, const float* feat, cons
 int gso_backward_sums(const gso_frame* f, const float* grad_image, float* sums, float* mag_img)
 {
     gso_acc acc = acc_alloc(f->M, 0);
-    backward_loop1(f, grad_image, mag_img, acc);
+    backward_loop1(f, grad_image, mag_img, acc, 1);
     pack_sums(f->M, acc, sums);
     acc_free(acc);
     return 0;

@@ -47,7 +47,24 @@ typedef struct gso_config {
     int   radius_from_preblur_cov;   /* SURVEY 8a a5-vii switch; 1 = Taichi by-value semantics */
     int   allow_partial_tiles;       /* EXTENSION (not in the reference, which asserts W,H % 16 == 0): the last tile
                                         row/column may be partly outside the image; tile counts are rounded up */
+    int   blend_exp;                 /* which exp the two blend loops use for the Gaussian falloff (RAST:441-452, UTIL:275-284,
+                                        UTIL:331-348; `ti.exp` there, compiled by Taichi with fast-math to the GPU's fast exp):
+                                        GSO_EXP_POLY (0, default) = gso_exp_blend, the sequence libgsrast shares bit for bit;
+                                        GSO_EXP_LIBM (1) = libm expf (correctly rounded to < 1 ulp);
+                                        GSO_EXP_FAST2 (2) = exp2f(x * log2(e)) with the product rounded to f32 first, the shape of
+                                        CUDA's __expf; GSO_EXP_ULP2 (3) = that result moved by a pseudo-random -2..+2 ulp, the error
+                                        a hardware approximation unit (ex2.approx: 2 ulp) is allowed.  1..3 exist to MEASURE how much the choice of exp moves the index outputs
+                                        (tests/test_oracle_exp_sensitivity.py); the HIP path is compared against 0 only. */
+    int   bwd_strict_dpdcov;         /* loop 1's d p / d Sigma' (UTIL:343-345).  1 (default) = the reference's own f32 operation
+                                        order, 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two 2x2 products; 0 = the algebraically equal
+                                        v v^T with v = Sigma^-1 d that libgsrast's default (fast) backward evaluates.  The 0 form
+                                        exists to show, on the CPU alone, that this one expression is what separates the two
+                                        (tests/test_oracle_exp_sensitivity.py::test_dpdcov_order_is_the_soak_gap). */
 } gso_config;
+#define GSO_EXP_POLY 0
+#define GSO_EXP_LIBM 1
+#define GSO_EXP_FAST2 2
+#define GSO_EXP_ULP2 3
 
 /* Everything the forward produces, in the reference's own layouts. */
 typedef struct gso_frame {
@@ -76,6 +93,7 @@ typedef struct gso_frame {
     float*   pixel_accumulated_alpha; /* (H,W) */
     int32_t* pixel_offset_of_last_effective_point; /* (H,W) */
     int32_t* pixel_valid_point_count; /* (H,W) */
+    int32_t  blend_exp;             /* the gso_config.blend_exp this frame was blended with: its backward uses the same one */
 } gso_frame;
 
 /* f32 exp used everywhere the reference writes ti.exp / ti.math.exp.

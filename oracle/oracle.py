@@ -24,12 +24,16 @@ class Config(C.Structure):
         ("grad_color_factor", C.c_float), ("grad_high_order_color_factor", C.c_float),
         ("grad_s_factor", C.c_float), ("grad_q_factor", C.c_float),
         ("grad_alpha_factor", C.c_float), ("radius_from_preblur_cov", C.c_int), ("allow_partial_tiles", C.c_int),
+        ("blend_exp", C.c_int), ("bwd_strict_dpdcov", C.c_int),
     ]
+
+
+EXP_POLY, EXP_LIBM, EXP_FAST2, EXP_ULP2 = 0, 1, 2, 3      # gso_config.blend_exp (gs_oracle.h)
 
 
 def default_config(**kw):
     """Reference defaults, GaussianPointCloudRasterisation.py:776-786."""
-    c = Config(0.8, 1000.0, 100.0, 0, 5.0, 1.0, 0.5, 1.0, 20.0, 1, 0)
+    c = Config(0.8, 1000.0, 100.0, 0, 5.0, 1.0, 0.5, 1.0, 20.0, 1, 0, EXP_POLY, 1)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -53,6 +57,7 @@ class _Frame(C.Structure):
         ("tile_points_start", _I32), ("tile_points_end", _I32),
         ("rasterized_image", _F), ("rasterized_depth", _F), ("pixel_accumulated_alpha", _F),
         ("pixel_offset_of_last_effective_point", _I32), ("pixel_valid_point_count", _I32),
+        ("blend_exp", C.c_int32),
     ]
 
 
