@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 6
+#define GS_ABI_VERSION 7
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -59,6 +59,15 @@ typedef struct gs_config {
     float   grad_alpha_factor;               /* 20    */
     int32_t allow_partial_tiles;             /* 0; EXTENSION: 1 lifts the W,H % 16 == 0 requirement (RAST:1193-1194): tile
                                                 counts are rounded up and pixels outside the image do not exist */
+    int32_t bwd_reference_order;             /* 0; 1 = the backward's per-contribution Gaussian gradient
+                                                (grad_point_probability_density_from_conic_and_rescale, utils.py:331-348) in the
+                                                reference's own f32 operation order: Sigma^-1 d without fused multiply-adds and
+                                                d p / d Sigma' as 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two 2x2 products.  The
+                                                default forms the same matrix as v v^T, v = Sigma^-1 d (three fused multiply-adds;
+                                                for long thin conics closer to exact arithmetic than the reference's rounding,
+                                                and up to 1.5e-4 of the tensor maximum away from it on such scenes).  Read by
+                                                gs_backward from the config passed to it, by gs_backward_projected from the
+                                                config its frame was made with.  ~25 % slower blend backward. */
 } gs_config;
 
 /* The point-cloud half of GaussianPointCloudRasterisationInput, RAST:788-804. */
@@ -102,7 +111,13 @@ typedef struct gs_frame_info {
     int32_t sort_key_bits;          /* significant bits actually radix-sorted */
     int32_t kept_for_backward;
     int32_t stages;                 /* GS_STAGE_PROJECT | GS_STAGE_RASTER: which halves of the path the frame holds */
+    int32_t sizing;                 /* how the per-pixel half of the forward was sized (see gs_forward): GS_SIZING_EXACT,
+                                       GS_SIZING_PREDICTED or GS_SIZING_REDONE */
 } gs_frame_info;
+
+#define GS_SIZING_EXACT     0       /* the host waited for M, K and the depth-code range before it queued binning, sort and blend */
+#define GS_SIZING_PREDICTED 1       /* queued without waiting, on the buffer capacities and key width the context already had; held */
+#define GS_SIZING_REDONE    2       /* the prediction did not hold (K beyond the buffers, or wider depth codes): queued again */
 
 #define GS_STAGE_PROJECT 1          /* filter + compaction + projection (gs_forward, gs_project_shard) */
 #define GS_STAGE_RASTER  2          /* binning + sort + blend (gs_forward, gs_forward_projected) */
@@ -278,6 +293,10 @@ int gs_adam_step(gs_ctx* ctx, float* param, const float* grad, float* exp_avg, f
 
 /* Bytes of device memory the context currently owns (arena + frames). */
 int64_t gs_ctx_device_bytes(const gs_ctx* ctx);
+
+/* Diagnostic: nanoseconds the host has spent so far, over all calls on this ctx, waiting for a frame's counters (M, K,
+ * depth-code range) to arrive from the device -- the one host dependency of a forward (tools/host_timeline.py). */
+int64_t gs_ctx_counter_wait_ns(const gs_ctx* ctx);
 
 /* Names of the kernels one forward+backward launches, comma separated; the position of a
  * name is its kernel id in the two calls below. */

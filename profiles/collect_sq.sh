@@ -29,7 +29,9 @@ for k, v in acc.items():
     res[k]["issue_stall_over_wave_cycles"] = round(m.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
     idx = m.get("SQ_LDS_IDX_ACTIVE", 0.0)
     res[k]["lds_bank_conflict_fraction"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / idx, 4) if idx else None
-doc = {"workload": wl, "note": "per-launch averages; ratios are per wave (quad-cycle units cancel)", "kernels": res}
+sys.path.insert(0, os.getcwd())
+from taichi_3d_gaussian_splatting_amd import _native
+doc = {"workload": wl, "source_digest": _native.source_digest(), "note": "per-launch averages; ratios are per wave (quad-cycle units cancel)", "kernels": res}
 json.dump(doc, open(dst, "w"), indent=1, sort_keys=True)
 json.dump(doc, open(os.path.join(os.path.dirname(dst), "sq_counters.json"), "w"), indent=1, sort_keys=True)   # the copy bench.py reads
 for k in ("k_blend_bwd_tile", "k_blend_fwd", "k_sort_scatter", "k_bwd_points"):

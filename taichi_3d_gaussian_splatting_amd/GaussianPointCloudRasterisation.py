@@ -81,9 +81,10 @@ class _Frame:
         _native.check(_native.lib().gs_frame_get_info(self._context.handle, self.handle, C.byref(info)), "gs_frame_get_info")
         self.n_points, self.n_points_in_camera, self.n_keys = info.n_points, info.n_points_in_camera, info.n_keys
         self.n_tiles, self.sort_key_bits, self.stages = info.n_tiles, info.sort_key_bits, info.stages
+        self.sizing = ("exact", "predicted", "redone")[info.sizing]      # gs_frame_info.sizing: how the per-pixel half was sized
 
     def __getattr__(self, name):            # only reached for attributes not set yet: the counts of a lazy frame
-        if name in ("n_points", "n_points_in_camera", "n_keys", "n_tiles", "sort_key_bits", "stages"):
+        if name in ("n_points", "n_points_in_camera", "n_keys", "n_tiles", "sort_key_bits", "stages", "sizing"):
             self._read_info()
             return self.__dict__[name]
         raise AttributeError(name)
@@ -139,6 +140,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         grad_alpha_factor = 20.
         # extension over the reference: True lifts the W,H % 16 == 0 requirement (e.g. a true 1920x1080 frame)
         allow_partial_tiles = False
+        # extension: True runs the backward's per-contribution Gaussian gradient (utils.py:331-348) in the reference's own f32
+        # operation order instead of the faster, algebraically equal form (gs_config.bwd_reference_order)
+        backward_reference_order = False
 
     @dataclass
     class GaussianPointCloudRasterisationInput:
@@ -237,7 +241,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         c = self.config
         return _native.GsConfig(c.near_plane, c.far_plane, c.depth_to_sort_key_scale, 1 if c.rgb_only else 0,
                                 c.grad_color_factor, c.grad_high_order_color_factor, c.grad_s_factor,
-                                c.grad_q_factor, c.grad_alpha_factor, 1 if getattr(c, "allow_partial_tiles", False) else 0)
+                                c.grad_q_factor, c.grad_alpha_factor, 1 if getattr(c, "allow_partial_tiles", False) else 0,
+                                1 if getattr(c, "backward_reference_order", False) else 0)
 
     @staticmethod
     def _c_scene(pointcloud, features, mask, obj):
@@ -310,7 +315,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 pointcloud.data_ptr() or None, features.data_ptr() or None, mask.data_ptr() or None, obj.data_ptr() or None, pointcloud.shape[0],
                 q.data_ptr() or None, t.data_ptr() or None):
             ms = self._marshal(pointcloud, features, mask, obj, q, t, camera_info)     # storage was swapped since the forward (p.data = ...)
-        scene, cam, cfg = ms
+        scene, cam, _ = ms
+        cfg = self._c_config()          # read again: the grad factors (and bwd_reference_order) may have changed since the forward
         if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (H, W, 3):
             raise ValueError("grad of rasterized_image must be float32 (H,W,3)")
         # one allocation for both gradients so that data-parallel training all-reduces ONE buffer; the 56-float rows

@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
 LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -20,7 +20,7 @@ class GsConfig(C.Structure):
     _fields_ = [("near_plane", _F32), ("far_plane", _F32), ("depth_to_sort_key_scale", _F32),
                 ("rgb_only", _I32), ("grad_color_factor", _F32), ("grad_high_order_color_factor", _F32),
                 ("grad_s_factor", _F32), ("grad_q_factor", _F32), ("grad_alpha_factor", _F32),
-                ("allow_partial_tiles", _I32)]
+                ("allow_partial_tiles", _I32), ("bwd_reference_order", _I32)]
 
 
 class GsScene(C.Structure):
@@ -41,7 +41,7 @@ class GsForwardOut(C.Structure):
 class GsFrameInfo(C.Structure):
     _fields_ = [("n_points", _I64), ("n_points_in_camera", _I64), ("n_keys", _I64), ("n_tiles", _I32),
                 ("camera_height", _I32), ("camera_width", _I32), ("sort_key_bits", _I32),
-                ("kept_for_backward", _I32), ("stages", _I32)]
+                ("kept_for_backward", _I32), ("stages", _I32), ("sizing", _I32)]
 
 
 STAGE_PROJECT, STAGE_RASTER = 1, 2
@@ -88,11 +88,25 @@ EXPORTS = {
 # every symbol include/gs_rasterizer.h declares
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
-           "gs_ctx_device_bytes", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
+           "gs_ctx_device_bytes", "gs_ctx_counter_wait_ns", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
            "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
            "gs_project_shard", "gs_project_shard_begin", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
 
 _lib = None
+
+
+def source_digest():
+    """sha256 (12 hex digits) over the kernel sources and the ABI header: what a profile taken with one build of the library is
+    labelled with, so that counters are never quoted beside another build's timings (bench.py: roofline.traffic / .valu)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "gs_rasterizer.h"), "rb").read())
+    return h.hexdigest()[:12]
 
 
 class NativeLibraryError(RuntimeError):
@@ -152,6 +166,8 @@ def lib():
     L.gs_adam_step.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _I64, _VP]
     L.gs_profile_read.argtypes = [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32, _I32]
     L.gs_ctx_device_bytes.restype = _I64
+    L.gs_ctx_counter_wait_ns.argtypes = [_VP]
+    L.gs_ctx_counter_wait_ns.restype = _I64
     if L.gs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH} has ABI {L.gs_abi_version()}, this package expects {ABI_VERSION}")
     _lib = L

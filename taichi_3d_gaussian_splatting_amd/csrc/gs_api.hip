@@ -4,6 +4,7 @@
 #include "../../include/gs_rasterizer.h"
 #include "gs_common.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -71,6 +72,7 @@ struct Frame {
     int key64 = 0;
     int32_t* vals_sorted = nullptr;
     bool live = false;
+    int bwd_reference_order = 0;        // gs_config.bwd_reference_order of the forward that made the frame (gs_backward_projected has no config)
     uint32_t generation = 0;
     // gs_project_shard_begin: the hand-over of M (and the object-id check) has not been read yet; slot of the pinned counters
     // the frame's publish kernel writes, its ticket and the stream to fall back on
@@ -123,6 +125,10 @@ struct gs_ctx {
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
     uint64_t slots_busy = 1ull;            // slot 0 serves the calls that wait at once; the others belong to frames begun and not yet read
     int32_t ticket = 0;                    // sequence number of the last forward
+    int64_t counter_wait_ns = 0;           // host time spent waiting for frame counters so far (gs_ctx_counter_wait_ns)
+    // Predicted sizing of the per-pixel half (run_forward_tail): what the last frame of this ctx needed, for an image of this
+    // size.  The next frame's binning, sort and blend are queued on it without waiting for the frame's own counters.
+    struct { bool valid = false; int H = 0, W = 0; uint32_t K = 0; int max_code = 0; } seen;
     // dispatch order for the next forward blend: the last backward's tile order (heaviest first).  Only ever a complete
     // permutation of [0, order_hint_T) written by k_tile_order; 0 = none.  A hint only moves work in time.
     DevBuf order_hint;
@@ -211,6 +217,7 @@ extern "C" int gs_profile_read(gs_ctx* c, double* total_ms, int64_t* launches, i
 }
 
 extern "C" int64_t gs_ctx_device_bytes(const gs_ctx* c) { return c ? c->device_bytes : 0; }
+extern "C" int64_t gs_ctx_counter_wait_ns(const gs_ctx* c) { return c ? c->counter_wait_ns : 0; }
 
 // ---- frame tickets ------------------------------------------------------------------------------------------------
 static gs_frame* ticket_of(int slot, uint32_t generation)
@@ -304,7 +311,9 @@ static int wait_counters(gs_ctx* c, hipStream_t s, int32_t ticket, int slot = 0)
 {
     static const bool wait_on_stream = []{ const char* e = getenv("GS_COUNTERS_WAIT"); return e && std::strcmp(e, "stream") == 0; }();
     if (wait_on_stream) {                   // diagnostic alternative: block in the runtime instead of spinning
+        const auto t0s = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(s));
+        c->counter_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0s).count();
         return GS_OK;
     }
     volatile GsCounters* hc = c->host_counters + slot;
@@ -322,6 +331,7 @@ static int wait_counters(gs_ctx* c, hipStream_t s, int32_t ticket, int slot = 0)
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    c->counter_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return GS_OK;
 }
 
@@ -361,10 +371,28 @@ static int check_forward_out(const gs_forward_out* out, const gs_config* cfg, in
 }
 
 // ---- per-point half: filter, compaction, projection (+ tile counts, scan, publication) ----------------------------
-// On success the frame's buffers hold mask / ids / cam_index / records / box / ntiles and M, K, max_code are known.
-// defer: do not wait for the hand-over -- the frame keeps a counter slot and whoever needs M first reads it (resolve_pending).
+// On success the frame's buffers hold mask / ids / cam_index / records / box / ntiles.  The counters (M, K, depth-code range,
+// bad object ids) are handed over through pinned memory; `wait` says when the host reads them:
+//   WAIT_NOW    before this function returns (M, K, max_code are filled in);
+//   WAIT_LATER  the caller reads slot 0 itself (read_counters) after it has queued more work -- nothing else may publish before;
+//   WAIT_FRAME  the frame keeps a slot of its own and whoever needs M first reads it (resolve_pending, gs_project_shard_begin).
+enum CounterWait { WAIT_NOW, WAIT_LATER, WAIT_FRAME };
+
+static int read_counters(gs_ctx* c, Frame* f, hipStream_t s, int32_t ticket, int* M_out, uint32_t* K_out, int* max_code_out)
+{
+    const int rc = wait_counters(c, s, ticket);
+    if (rc != GS_OK) { drop_frame(c, f); return rc; }
+    if (c->host_counters->bad_object_ids != 0) {
+        drop_frame(c, f);
+        return fail(GS_ERR_INVALID_ARGUMENT, "point_object_id holds " + std::to_string(c->host_counters->bad_object_ids) +
+                                             " value(s) outside [0, n_objects) on valid rows");
+    }
+    *M_out = c->host_counters->M; *K_out = c->host_counters->K; *max_code_out = c->host_counters->max_depth_code;
+    return GS_OK;
+}
+
 static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_camera* cam, const gs_config* cfg, int T,
-                             hipStream_t s, GsProjectArgs* pa_out, int* M_out, uint32_t* K_out, int* max_code_out, bool defer = false)
+                             hipStream_t s, GsProjectArgs* pa_out, int* M_out, uint32_t* K_out, int* max_code_out, CounterWait wait = WAIT_NOW)
 {
     FrameBufs& B = *f->bufs;
     const int64_t N = sc->n_points;
@@ -395,7 +423,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
     int slot = 0;
-    if (defer && N > 0) {
+    if (wait == WAIT_FRAME && N > 0) {
         const uint64_t free_slots = ~c->slots_busy;
         if (free_slots != 0ull) { slot = __builtin_ctzll(free_slots); c->slots_busy |= 1ull << slot; }     // none left: wait at once
     }
@@ -404,46 +432,36 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     gs_launch_project(pa, s);
     HIP_TRY_F(hipGetLastError());
     *pa_out = pa;
+    *M_out = 0; *K_out = 0u; *max_code_out = 0;
     if (slot > 0) {
         f->pending_slot = slot; f->pending_ticket = pa.ticket; f->pending_stream = s;
-        *M_out = 0; *K_out = 0u; *max_code_out = 0;
         return GS_OK;
     }
-    if (N > 0) {
-        const int rc = wait_counters(c, s, pa.ticket);
-        if (rc != GS_OK) { drop_frame(c, f); return rc; }
-        if (c->host_counters->bad_object_ids != 0) {
-            drop_frame(c, f);
-            return fail(GS_ERR_INVALID_ARGUMENT, "point_object_id holds " + std::to_string(c->host_counters->bad_object_ids) +
-                                                 " value(s) outside [0, n_objects) on valid rows");
-        }
-    }
-    *M_out = N > 0 ? c->host_counters->M : 0;
-    *K_out = N > 0 ? c->host_counters->K : 0u;
-    *max_code_out = N > 0 ? c->host_counters->max_depth_code : 0;
-    *pa_out = pa;
+    if (N > 0 && wait != WAIT_LATER) return read_counters(c, f, s, pa.ticket, M_out, K_out, max_code_out);
     return GS_OK;
 }
 
 // ---- per-pixel half: key build, sort, tile ranges, blend ----------------------------------------------------------
-static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_t n_rows, int M, uint32_t K, int max_code,
+// K_bound: pair capacity the buffers and the launch geometry are sized for; depth_bits: width of the depth field of the keys.
+// Both may be PREDICTIONS (run_forward_tail): the kernels take the frame's real pair count from the device counters and stay
+// inside K_bound whatever it is, and any depth_bits >= the real width sorts into the same order.
+static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_t n_rows, int M_bound, uint32_t K_bound, int depth_bits,
                             int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s)
 {
     FrameBufs& B = *f->bufs;
-    if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
-    const int depth_bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
     const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
     const int key64 = depth_bits + tile_bits > 32 ? 1 : 0;      // compact 32-bit keys whenever they fit
     if (depth_bits + tile_bits > 63) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "sort key needs more than 63 bits"); }
-    const size_t Kp = K > 0 ? K : 1;
+    const size_t Kp = K_bound > 0 ? K_bound : 1;
     const size_t key_bytes = key64 ? 8 : 4;
     ENSURE(B.keys_a, key_bytes * Kp); ENSURE(B.keys_b, key_bytes * Kp); ENSURE(B.vals_a, 4 * Kp); ENSURE(B.vals_b, 4 * Kp);
-    const size_t hist_elems = gs_sort_hist_elems(K);
+    const size_t hist_elems = gs_sort_hist_elems(K_bound);
     ENSURE(c->hist, 4 * hist_elems); ENSURE(c->scan_tmp, 4 * gs_scan_tmp_elems(hist_elems));
 
     GsBinArgs ba{};
     ba.prof = &c->prof;
-    ba.N = n_rows; ba.M = M; ba.K = K; ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
+    ba.N = n_rows; ba.M = M_bound; ba.K = K_bound; ba.counters = c->counters.as<GsCounters>();
+    ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
     ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.depth_codes = pa.depth_codes; ba.tile_block_offsets = pa.tile_block_offsets;
     ba.block_offsets = pa.block_offsets; ba.block_counts = pa.block_counts;     // NULL for records that did not come from k_project
@@ -460,7 +478,7 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     fa.prof = &c->prof;
     fa.H = H; fa.W = W; fa.tiles_x = tiles_x; fa.T = T; fa.rgb_only = cfg->rgb_only;
     fa.tile_start = ba.tile_start; fa.tile_end = ba.tile_end; fa.vals_sorted = f->vals_sorted;
-    fa.keys_sorted = f->keys_sorted; fa.key64 = key64; fa.depth_bits = depth_bits; fa.K = K;
+    fa.keys_sorted = f->keys_sorted; fa.key64 = key64; fa.depth_bits = depth_bits; fa.K = K_bound; fa.counters = ba.counters;
     fa.PA = pa.PA; fa.PB = pa.PB; fa.PC = pa.PC;
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
     fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;
@@ -473,6 +491,61 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     f->depth_bits = depth_bits;
     f->key64 = key64;
     f->info.sort_key_bits = depth_bits + tile_bits;
+    return GS_OK;
+}
+
+// Everything of a forward after the per-point kernels have been QUEUED (their counters not yet read): the per-pixel half and
+// the one device->host hand-over of the frame.
+//
+// The reference stops twice per forward to learn M and K on the host (RAST:870, 916-931).  Here the host needs them only to
+// size buffers and grids, so in steady state it does not stop in the middle at all: binning, sort and blend are queued at
+// once on PREDICTED sizes -- pair capacity = what the last frame of this ctx needed + 25 %, key width from the last frame's
+// depth-code range + 25 % -- and the hand-over is read AFTER the last launch,
+// when the GPU has the whole forward in its queue instead of nothing.  The kernels read the real pair count on the device and
+// never leave the predicted capacity, so a wrong prediction is harmless: the host sees it in the counters (K beyond the
+// capacity, or depth codes wider than the key field), grows the buffers and queues the per-pixel half again with the exact
+// sizes before the call returns (GS_SIZING_REDONE; the caller's outputs are simply written a second time, in stream order).
+// The first frame of a ctx, a new image size and GS_PREDICT_SIZES=0 take the exact path: wait, then queue (GS_SIZING_EXACT).
+static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_t n_rows, int M_known, int32_t ticket,
+                            int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s,
+                            int* M_out, uint32_t* K_out)
+{
+    static const bool predict = []{ const char* e = getenv("GS_PREDICT_SIZES"); return !(e && e[0] == '0'); }();
+    int rc, M = 0, max_code = 0; uint32_t K = 0;
+    f->info.sizing = GS_SIZING_EXACT;
+    if (n_rows == 0) {                                     // nothing was published: an empty frame
+        if ((rc = run_raster_stage(c, f, pa, 0, 0, 0u, 1, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+        *M_out = 0; *K_out = 0u;
+        return GS_OK;
+    }
+    const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
+    if (predict && c->seen.valid && c->seen.H == H && c->seen.W == W) {
+        const int bits_p = bits_for((uint32_t)(c->seen.max_code + c->seen.max_code / 4));
+        const uint64_t want = (uint64_t)c->seen.K + c->seen.K / 4 + 4096;      // buffers grow to this if they have to (once)
+        const uint32_t K_p = (uint32_t)std::min<uint64_t>(want, 0x7fffffffu);
+        if (K_p > 0 && bits_p + tile_bits <= 63) {
+            if ((rc = run_raster_stage(c, f, pa, n_rows, M_known >= 0 ? M_known : (int)n_rows, K_p, bits_p, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+            if ((rc = read_counters(c, f, s, ticket, &M, &K, &max_code)) != GS_OK) return rc;
+            if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
+            const int bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
+            if (K <= K_p && bits <= bits_p) {
+                f->info.sizing = GS_SIZING_PREDICTED;
+            } else {
+                // the per-pixel half ran on sizes that did not hold: its results are void (not out of bounds).  Again, exactly.
+                HIP_TRY_F(hipMemsetAsync(pa.tile_arrays, 0, sizeof(int32_t) * (size_t)pa.tile_ints, s));
+                if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+                f->info.sizing = GS_SIZING_REDONE;
+            }
+            c->seen.valid = true; c->seen.H = H; c->seen.W = W; c->seen.K = K; c->seen.max_code = max_code;
+            *M_out = M; *K_out = K;
+            return GS_OK;
+        }
+    }
+    if ((rc = read_counters(c, f, s, ticket, &M, &K, &max_code)) != GS_OK) return rc;
+    if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
+    if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits_for((uint32_t)(max_code > 0 ? max_code : 0)), H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    c->seen.valid = true; c->seen.H = H; c->seen.W = W; c->seen.K = K; c->seen.max_code = max_code;
+    *M_out = M; *K_out = K;
     return GS_OK;
 }
 
@@ -507,8 +580,9 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     const int T = tiles_x * tiles_y;
     GsProjectArgs pa{};
     int M = 0, max_code = 0; uint32_t K = 0;
-    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code)) != GS_OK) return rc;
-    if ((rc = run_raster_stage(c, f, pa, sc->n_points, M, K, max_code, cam->camera_height, cam->camera_width, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code, WAIT_LATER)) != GS_OK) return rc;
+    if ((rc = run_forward_tail(c, f, pa, sc->n_points, -1, pa.ticket, cam->camera_height, cam->camera_width, tiles_x, T, cfg, out, s, &M, &K)) != GS_OK) return rc;
+    f->bwd_reference_order = cfg->bwd_reference_order;
     finish_frame(c, f, slot, sc->n_points, M, K, T, cam->camera_height, cam->camera_width, keep, GS_STAGE_PROJECT | GS_STAGE_RASTER, frame_out);
     return GS_OK;
 }
@@ -583,7 +657,7 @@ extern "C" int gs_project_shard_begin(gs_ctx* c, const gs_scene* sc, const gs_ca
     const int T = tiles_x * tiles_y;
     GsProjectArgs pa{};
     int M = 0, max_code = 0; uint32_t K = 0;
-    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code, true)) != GS_OK) return rc;
+    if ((rc = run_project_stage(c, f, sc, cam, cfg, T, s, &pa, &M, &K, &max_code, WAIT_FRAME)) != GS_OK) return rc;
     finish_frame(c, f, slot, sc->n_points, M, K, T, cam->camera_height, cam->camera_width, keep, GS_STAGE_PROJECT, frame_out);
     return GS_OK;
 }
@@ -625,12 +699,9 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_boxes_from_records(pa, (int)m, s);
     HIP_TRY_F(hipGetLastError());
-    uint32_t K = 0; int max_code = 0;
-    if (m > 0) {
-        if ((rc = wait_counters(c, s, pa.ticket)) != GS_OK) { drop_frame(c, f); return rc; }
-        K = c->host_counters->K; max_code = c->host_counters->max_depth_code;
-    }
-    if ((rc = run_raster_stage(c, f, pa, m, (int)m, K, max_code, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    uint32_t K = 0; int M_seen = 0;
+    if ((rc = run_forward_tail(c, f, pa, m, (int)m, pa.ticket, H, W, tiles_x, T, cfg, out, s, &M_seen, &K)) != GS_OK) return rc;
+    f->bwd_reference_order = cfg->bwd_reference_order;
     finish_frame(c, f, slot, m, (int)m, K, T, H, W, keep, GS_STAGE_RASTER, frame_out);
     return GS_OK;
 }
@@ -734,7 +805,7 @@ static int waves_per_tile(int n_tiles)
 
 // fills the blend half of the arguments; sums_out = where the per-splat sums go
 static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_image, const float* acc_alpha, const int32_t* last,
-                                  float* mag_image, float4* sums_out, GsBackwardArgs* a_out)
+                                  float* mag_image, float4* sums_out, int strict, GsBackwardArgs* a_out)
 {
     const uint32_t K = (uint32_t)f->info.n_keys;
     const int G = waves_per_tile(f->info.n_tiles);
@@ -765,6 +836,7 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
     a.G = G;
+    a.strict = strict ? 1 : 0;
     a.visited_bytes = flag_bytes + 64 + Mp;
     a.touched = c->visited.as<uint8_t>() + flag_bytes + 64;
     a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + flag_bytes);
@@ -837,7 +909,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* h, const gs_scene* sc, const gs_
     if (c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes) != hipSuccess)
         return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
     GsBackwardArgs a{};
-    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), &a)) != GS_OK) return rc;
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), cfg->bwd_reference_order, &a)) != GS_OK) return rc;
     if ((rc = prepare_backward_points(f, sc, cam, cfg, sh_band, out, c->sums.as<float4>(), &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
     if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
@@ -863,7 +935,7 @@ extern "C" int gs_backward_projected(gs_ctx* c, gs_frame* h, const float* grad_i
     HIP_TRY(enter_stream(c, s));
     GsBackwardArgs a{};
     int rc;
-    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), &a)) != GS_OK) return rc;
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), f->bwd_reference_order, &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
     if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
     HIP_TRY(hipGetLastError());

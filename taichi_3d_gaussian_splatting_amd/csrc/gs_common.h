@@ -223,7 +223,10 @@ void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s);
 
 struct GsBinArgs {
     GsProf* prof;
-    int64_t N; int M; uint32_t K; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
+    // M and K are BOUNDS here: the per-pixel half may be queued before the host has read the frame's counters (gs_api.hip,
+    // "predicted sizing").  M bounds the in-camera offsets (N rows when unknown); K is the pair capacity the launch geometry and
+    // the buffers were sized for -- every kernel works on min(counters->K, K) pairs, read on the device.
+    int64_t N; int M; uint32_t K; const GsCounters* counters; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
     const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const int32_t* depth_codes; const uint32_t* tile_block_offsets;
     const int32_t *block_offsets, *block_counts;   // k_project's blocks (first in-camera offset, count); NULL: 256 consecutive records per block
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
@@ -242,7 +245,7 @@ struct GsBlendFwdArgs {
     GsProf* prof;
     int H, W, tiles_x, T; int rgb_only;
     int32_t *tile_start, *tile_end;      // written by the blend kernel itself (each tile's block finds its range in the sorted keys)
-    const void* keys_sorted; int key64, depth_bits; uint32_t K;
+    const void* keys_sorted; int key64, depth_bits; uint32_t K; const GsCounters* counters;   // min(counters->K, K) pairs (see GsBinArgs)
     const int32_t* vals_sorted;
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
@@ -261,6 +264,7 @@ struct GsBackwardArgs {
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;
     int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
+    int strict;                     // gs_config.bwd_reference_order: loop 1's UTIL:331-348 in the reference's own operation order
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
     uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward
     size_t visited_bytes;           // flags (K*G rounded up to 16), one all-zero 48-byte row, 16 bytes of padding, then `touched`: all cleared per backward

@@ -86,7 +86,15 @@ struct QuadState { float T, W, gr, gg, gb, tot0, tot1; int last; };
 
 // NQ = quadrants per wave: 4 (one wave per tile), 2 (two waves per tile, upper / lower half) or 1.
 // With G = 4/NQ waves per tile every (point, tile) pair owns G consecutive rows of `partial`.
-template <int NQ>
+// STRICT (gs_config.bwd_reference_order): grad_point_probability_density_from_conic_and_rescale in the reference's own f32
+// operation order (UTIL:331-348) -- Sigma^-1 d without fused multiply-adds, the falloff through the reference polynomial for
+// every lane, and d p / d Sigma' as 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two 2x2 matrix products, like
+// the CPU oracle (test infrastructure).  The default (fast) form takes the same matrix as v v^T with v = Sigma^-1 d: three fused
+// multiply-adds instead of 24 operations, and for a long thin conic -- where a*dx and b*dy cancel in Sigma^-1 d -- more
+// accurate than the reference's own rounding, which is why three ill-conditioned soak scenes sit 1.05e-4 .. 1.5e-4 of the tensor
+// maximum from the oracle in the fast form and at the summation-order floor in this one
+// (tests/test_gpu_parity.py::test_soak_seeds_with_ill_conditioned_splats, profiles/r03_strict_vs_fast.json).
+template <int NQ, bool STRICT>
 __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order,
                                                        const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                        const int32_t* __restrict__ sorted_vals,
@@ -202,18 +210,33 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                         // some lane sits within 1e-5 of the 1/255 threshold every keep/skip decision is already the oracle's;
                         // otherwise the strict sequence and the reference polynomial decide.
                         const float dx = pxq[qi] - a4.x, dy = pyq[qi] - a4.y;
-                        const float cix = __builtin_fmaf(a, dx, b * dy), ciy = __builtin_fmaf(b, dx, c * dy);
-                        // exp(-0.5 * q) = 2^(q * (-0.5 * log2 e)): one multiply instead of two
-                        float g = __builtin_amdgcn_exp2f(__builtin_fmaf(dx, cix, dy * ciy) * -0.72134752044448170f) * b4.y;
-                        float prod_alpha = g * apt;
-                        // RAST:634 against both edges of the band: where the two votes agree no lane is inside it (two compares, no subtraction)
-                        unsigned long long use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS + 4.0e-8f) & inr_m;
-                        if (use_m != (gs_ballot(prod_alpha >= GS_ALPHA_EPS - 4.0e-8f) & inr_m)) {
-                            const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
-                            g = gs_exp_blend(-0.5f * (dx * sx + dy * sy)) * b4.y;
+                        float cix, ciy, g, prod_alpha;
+                        float m00 = 0.0f, m01 = 0.0f, m11 = 0.0f;                 // Sigma^-1 (d d^T) Sigma^-1 (STRICT only)
+                        unsigned long long use_m;
+                        if (STRICT) {
+                            // UTIL:331-348 as written (no contraction: file default)
+                            cix = a * dx + b * dy; ciy = b * dx + c * dy;
+                            g = gs_exp_blend(-0.5f * (dx * cix + dy * ciy)) * b4.y;
+                            const float oxx = dx * dx, oxy = dx * dy, oyx = dy * dx, oyy = dy * dy;
+                            const float io00 = a * oxx + b * oyx, io01 = a * oxy + b * oyy;
+                            const float io10 = b * oxx + c * oyx, io11 = b * oxy + c * oyy;
+                            m00 = io00 * a + io01 * b; m01 = io00 * b + io01 * c; m11 = io10 * b + io11 * c;
                             prod_alpha = g * apt;
-                            use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;
-                            GS_STAT(14, 1);
+                            use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;       // RAST:634
+                        } else {
+                            cix = __builtin_fmaf(a, dx, b * dy); ciy = __builtin_fmaf(b, dx, c * dy);
+                            // exp(-0.5 * q) = 2^(q * (-0.5 * log2 e)): one multiply instead of two
+                            g = __builtin_amdgcn_exp2f(__builtin_fmaf(dx, cix, dy * ciy) * -0.72134752044448170f) * b4.y;
+                            prod_alpha = g * apt;
+                            // RAST:634 against both edges of the band: where the two votes agree no lane is inside it (two compares, no subtraction)
+                            use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS + 4.0e-8f) & inr_m;
+                            if (use_m != (gs_ballot(prod_alpha >= GS_ALPHA_EPS - 4.0e-8f) & inr_m)) {
+                                const float sx = a * dx + b * dy, sy = b * dx + c * dy;      // no contraction here (file default)
+                                g = gs_exp_blend(-0.5f * (dx * sx + dy * sy)) * b4.y;
+                                prod_alpha = g * apt;
+                                use_m = gs_ballot(prod_alpha >= GS_ALPHA_EPS) & inr_m;
+                                GS_STAT(14, 1);
+                            }
                         }
                         n_use += __popcll(use_m);
                         GS_STAT(12, __popcll(use_m)); GS_STAT(15, use_m != 0ull ? 1 : 0);
@@ -236,7 +259,8 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             const float agg = ag * gg;
                             const float vs0 = agg * cix, vs1 = agg * ciy;
                             v[0] = vs0; v[1] = vs1;
-                            v[2] = vs0 * cix; v[3] = vs0 * ciy; v[4] = vs1 * ciy;
+                            if (STRICT) { v[2] = agg * m00; v[3] = agg * m01; v[4] = agg * m11; }
+                            else { v[2] = vs0 * cix; v[3] = vs0 * ciy; v[4] = vs1 * ciy; }
                             v[5] = d_rgb * Q[qi].gr; v[6] = d_rgb * Q[qi].gg; v[7] = d_rgb * Q[qi].gb;
                             v[8] = agg;
                             v[9] = __builtin_amdgcn_sqrtf(vs0 * vs0 + vs1 * vs1);
@@ -261,9 +285,13 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                             const float agg = ag * g;
                             const float vs0 = agg * cix, vs1 = agg * ciy;       // RAST:664-665 without the opacity factor
                             v[0] += vs0; v[1] += vs1;
-                            v[2] = __builtin_fmaf(vs0, cix, v[2]);
-                            v[3] = __builtin_fmaf(vs0, ciy, v[3]);
-                            v[4] = __builtin_fmaf(vs1, ciy, v[4]);
+                            if (STRICT) {
+                                v[2] = __builtin_fmaf(agg, m00, v[2]); v[3] = __builtin_fmaf(agg, m01, v[3]); v[4] = __builtin_fmaf(agg, m11, v[4]);
+                            } else {
+                                v[2] = __builtin_fmaf(vs0, cix, v[2]);
+                                v[3] = __builtin_fmaf(vs0, ciy, v[3]);
+                                v[4] = __builtin_fmaf(vs1, ciy, v[4]);
+                            }
                             v[5] = __builtin_fmaf(d_rgb, Q[qi].gr, v[5]);         // RAST:650
                             v[6] = __builtin_fmaf(d_rgb, Q[qi].gg, v[6]);
                             v[7] = __builtin_fmaf(d_rgb, Q[qi].gb, v[7]);
@@ -690,15 +718,14 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         const unsigned clear_groups = (unsigned)((clear_vec + 4095) / 4096 < 1024 ? (clear_vec + 4095) / 4096 : 1024);
         GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint,
                                                                                          reinterpret_cast<uint4*>(a.visited), clear_vec));
-        if (a.G == 1)
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<4><<<a.T, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
-        else if (a.G == 2)
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<2><<<a.T * 2, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
-        else
-            GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<1><<<a.T * 4, 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box,
-                     a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial, a.visited, a.touched, a.mag_image));
+#define GS_BWD_LAUNCH(NQ_, STRICT_, WAVES_)                                                                                           \
+        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<(WAVES_), 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end,   \
+                 a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial,      \
+                 a.visited, a.touched, a.mag_image))
+        if (a.G == 1) { if (a.strict) GS_BWD_LAUNCH(4, true, a.T); else GS_BWD_LAUNCH(4, false, a.T); }
+        else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true, a.T * 2); else GS_BWD_LAUNCH(2, false, a.T * 2); }
+        else { if (a.strict) GS_BWD_LAUNCH(1, true, a.T * 4); else GS_BWD_LAUNCH(1, false, a.T * 4); }
+#undef GS_BWD_LAUNCH
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
 }
 
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys, uint32_t n, int shift,
+__global__ __launch_bounds__(256) void k_sort_hist(const KeyT* __restrict__ keys, const GsCounters* __restrict__ ctr, uint32_t n_cap, int shift,
                                                    uint32_t* __restrict__ hist, int nblocks, int tiles_per_block)
 {
     __shared__ uint32_t lh[256];
+    const uint32_t n = min(ctr->K, n_cap);      // the frame's pair count, on the device (the launch may have been sized before the host knew it)
     lh[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * SORT_TILE;     // multiple of 4096: 16-byte aligned
@@ -151,9 +152,10 @@ __global__ __launch_bounds__(1024) void k_sort_rowscan(const uint32_t* __restric
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_sort_scatter(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out,
-                                                      uint32_t n, int shift, const uint32_t* __restrict__ hist_scanned,
+                                                      const GsCounters* __restrict__ ctr, uint32_t n_cap, int shift, const uint32_t* __restrict__ hist_scanned,
                                                       const uint32_t* __restrict__ totals, int nblocks, int tiles_per_block)
 {
+    const uint32_t n = min(ctr->K, n_cap);
     __shared__ uint32_t cnt[4][256];      // per-wave digit counts, then per-wave start inside the tile
     __shared__ uint32_t gbase[256];       // running global offset of each digit for this block
     __shared__ uint32_t dstart[256];      // start of each digit inside the sorted tile
@@ -298,9 +300,9 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     int32_t *vin = a.vals_a, *vout = a.vals_b;
     for (int shift = 0; shift < a.key_bits; shift += 8) {
         uint32_t* offs = a.hist + (size_t)256 * nb;                 // second half of the table: scanned offsets
-        GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.K, shift, a.hist, nb, tpb));
+        GS_TIMED(a.prof, KID_SORT_HIST, s, k_sort_hist<KeyT><<<nb, 256, 0, s>>>(kin, a.counters, a.K, shift, a.hist, nb, tpb));
         GS_TIMED(a.prof, KID_SORT_ROWSCAN, s, k_sort_rowscan<<<256, 1024, 0, s>>>(a.hist, a.scan_tmp, offs, nb));
-        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.K, shift, offs, a.scan_tmp, nb, tpb));
+        GS_TIMED(a.prof, KID_SORT_SCATTER, s, k_sort_scatter<KeyT><<<nb, 256, 0, s>>>(kin, vin, kout, vout, a.counters, a.K, shift, offs, a.scan_tmp, nb, tpb));
         KeyT* tk = kin; kin = kout; kout = tk;
         int32_t* tv = vin; vin = vout; vout = tv;
     }

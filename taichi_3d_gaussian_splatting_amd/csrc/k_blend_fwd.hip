@@ -38,7 +38,8 @@ __device__ __forceinline__ int gs_first_key_of_tile(const KeyT* __restrict__ key
 
 template <bool RGB_ONLY>
 __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_start, int32_t* __restrict__ tile_end,
-                                                   const void* __restrict__ sorted_keys, int key64, int depth_bits, uint32_t K,
+                                                   const void* __restrict__ sorted_keys, int key64, int depth_bits,
+                                                   const GsCounters* __restrict__ ctr, uint32_t K_cap,
                                                    const int32_t* __restrict__ sorted_vals,
                                                    const float4* __restrict__ PA, const float4* __restrict__ PB,
                                                    const float4* __restrict__ PC, int W, int H, int tiles_x,
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
                                                    const int32_t* __restrict__ order_hint)
 {
     __shared__ float4 sRec[4][64][3];          // the batch's splat records, one slab per wave
+    const uint32_t K = min(ctr->K, K_cap);     // pairs of this frame, read on the device (gs_api.hip: predicted sizing)
     // Dispatch order: heaviest tiles first when an earlier frame of this context left its ordering (same tile count) -- the
     // launch otherwise ends on the long walks of the image's dense region, started late.  Any permutation gives the same results.
     const int tile = order_hint ? order_hint[blockIdx.x] : (int)blockIdx.x;
@@ -183,9 +185,9 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
 {
     if (a.T <= 0) return;
     if (a.rgb_only)
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.counters, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
     else
-        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
+        GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.counters, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
                                                                               a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
 }

@@ -172,7 +172,7 @@ def gaussian_parallel_step(backend, grad_of_image, group=None):
     counts = torch.tensor(send_rows, dtype=torch.int64, device=recs[0].device)
     table = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(table, counts, group=group)                    # table[r'][v] = in-camera points of shard r' in view v
-    recv_rows = [int(table[r2][rank]) for r2 in range(world)]
+    recv_rows = torch.stack(table)[:, rank].tolist()       # ONE device->host read of the count table's column
     records = _all_to_all_rows(torch.cat(recs), send_rows, recv_rows, group)
     image, rhandle = backend.render(records)
     sums = backend.backward_render(rhandle, grad_of_image(image))

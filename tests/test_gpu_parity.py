@@ -510,68 +510,148 @@ def test_backward_through_depth_only_gives_zero_gradients(P):
 
 @pytest.mark.parametrize("seed", [60163, 60266, 141447])
 def test_soak_seeds_with_ill_conditioned_splats(P, seed):
-    """The two scenes of round 1's parity soak (tools/parity_soak.py; narrow, tall images full of huge anisotropic
-    splats; 2 of 340 such cases) where HIP and oracle are 1.1e-4 of the tensor maximum apart on the scale gradient --
-    over the tensor-level bar -- and the one such scene among the 7000 of round 2's soaks (1.3e-4 on the rotation gradient).  All three numbers are produced here: HIP vs oracle, HIP vs a float64 autograd
-    restatement (tests/torch_ref.py), oracle vs float64.
+    """The three scenes of the parity soaks (tools/parity_soak.py; narrow, tall images full of huge anisotropic splats; 3 of
+    ~9000 random scenes) where the DEFAULT backward and the oracle are more than 1e-4 of the tensor maximum apart (1.05e-4 /
+    1.14e-4 on the scale gradient, 1.3e-4 / 1.5e-4 on rotation and scale in the third) -- run in BOTH forms of the kernel.
 
-    Cause (found with the per-element metric, not the one round 1 named: k_bwd_points now follows the reference's
-    GP3D:270-330 product order like the oracle and the gap did not move): the reference forms d p / d Sigma' per
-    contribution as 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two f32 matrix products (UTIL:343-345), the oracle follows it,
-    and for a long thin conic a*dx and b*dy cancel in Sigma^-1 d, so the products carry an absolute error of
-    2^-24 (|a dx| + |b dy|)^2 against a value (a dx + b dy)^2 that is orders smaller.  k_blend_bwd_tile forms the same
-    quantity as v v^T with v = Sigma^-1 d (three fused multiply-adds instead of 24 operations in the kernel that
-    dominates the frame), which does not lose those digits: it agrees with float64 ten times better than the oracle
-    does.  Mirroring the reference's rounding there would cost ~40 % of the dominant kernel to be less accurate.
-    The per-element bar, whose floor is built from the un-cancelled magnitudes of exactly those products, holds against
-    the ORACLE in both scenes without any arbitration; the tensor-level figure is allowed 2e-4 here and nowhere else."""
+    Cause: the reference forms d p / d Sigma' per contribution as 0.5 p (Sigma^-1 (d d^T) Sigma^-1) with two f32 matrix
+    products (UTIL:343-345) and the oracle follows it; for a long thin conic a*dx and b*dy cancel in Sigma^-1 d, so those
+    products carry an absolute error of 2^-24 (|a dx| + |b dy|)^2 against a value (a dx + b dy)^2 that is orders smaller.
+    The default k_blend_bwd_tile forms the same matrix as v v^T with v = Sigma^-1 d (three fused multiply-adds instead of 24
+    operations in the kernel that dominates the frame) and keeps those digits.
+
+    Proof, not argument: with gs_config.bwd_reference_order = 1 the kernel evaluates UTIL:331-348 in the reference's own
+    order and the gap CLOSES -- every column group within 1e-5 of the tensor maximum of the oracle (what is left is the f32
+    summation order) -- while the default form shows the documented gap, sits several times closer to a float64 autograd
+    restatement than to the oracle, and the oracle sits as far from float64 as from the default form.  The same closure is
+    shown on the CPU alone by tests/test_oracle_exp_sensitivity.py::test_dpdcov_order_is_the_soak_gap.
+    The default form is a deliberate, documented deviation (include/gs_rasterizer.h: bwd_reference_order; DESIGN.md section 3;
+    distribution at configs 2 and 3 in profiles/r03_strict_vs_fast.json): its tensor-level bar in THESE three scenes is 2e-4,
+    the per-element bar (parity_util.py) holds without any allowance, and everywhere else in the suite it meets 1e-4."""
     import json
     import os
     # Seed 141447 (18 x 441 pixels, 747 splats in camera) is ill-conditioned all round: even where HIP and oracle agree to 4e-6
-    # (positions, opacity) both sit 3e-5 .. 8e-5 from float64, so its float64 bars are wider; the signature is the same --
-    # on q and s the oracle is 2e-4 from float64, HIP 5e-5, and they are 1.3e-4 / 1.5e-4 apart.
+    # (positions, opacity) both sit 3e-5 .. 8e-5 from float64, so its float64 bars are wider
     hip_f64_tol, orc_f64_tol, closer = (1e-4, 3e-4, 2.5) if seed == 141447 else (2e-5, 2e-4, 5.0)
     c = P.soak_case(seed)
     s, q, t, partial, rng = c["scene"], c["q"], c["t"], c["partial"], c["rng"]
     unit = dict(grad_color_factor=1.0, grad_high_order_color_factor=1.0, grad_s_factor=1.0, grad_q_factor=1.0, grad_alpha_factor=1.0)
-    cfg = P.Rast.GaussianPointCloudRasterisationConfig()
-    cfg.allow_partial_tiles = partial
-    for k, v in unit.items():
-        setattr(cfg, k, v)
-    module = P.Rast(cfg)
-    inp = P.make_input(s, q, t, 3)
     ocfg = oracle.default_config(allow_partial_tiles=int(partial), **unit)
     f, feat_after = P.run_oracle(s, q, t, ocfg)
-    outs = module(inp)
-    P.assert_forward_parity(module, inp, outs, f, feat_after)
-    image = outs[0]
-    target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
-    g = 2.0 * (image.detach() - target)
-    image.backward(g)
-    # HIP vs oracle: every element under the per-element bar; tensor level within 2e-4 (see above)
-    b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3, None, ocfg, tensor_tol=2e-4)
-    ref_pc, ref_ft = P.float64_autograd_gradients(s, q, t, f, feat_after, g.cpu().numpy())
-    gp, gf = inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()
-    op, of = b["grad_pointcloud"], b["grad_pointcloud_features"]
+    target = None
     report = {"seed": seed, "image": [c["W"], c["H"]], "points_in_camera": int(f.M), "metric": "max |a - b| / max |b| per column group"}
+    grads = {}
+    for form in ("fast", "reference_order"):
+        cfg = P.Rast.GaussianPointCloudRasterisationConfig()
+        cfg.allow_partial_tiles = partial
+        cfg.backward_reference_order = form == "reference_order"
+        for k, v in unit.items():
+            setattr(cfg, k, v)
+        module = P.Rast(cfg)
+        inp = P.make_input(s, q, t, 3)
+        outs = module(inp)
+        P.assert_forward_parity(module, inp, outs, f, feat_after)
+        image = outs[0]
+        if target is None:
+            target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
+        g = 2.0 * (image.detach() - target)
+        image.backward(g)
+        # every element under the per-element bar in both forms; tensor level: 1e-5 in the reference's order, 2e-4 in the fast form
+        b = P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3, None, ocfg, tensor_tol=1e-5 if form == "reference_order" else 2e-4)
+        grads[form] = (inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy(), b)
+    ref_pc, ref_ft = P.float64_autograd_gradients(s, q, t, f, feat_after, g.cpu().numpy())
+    gp, gf, b = grads["fast"]
+    sp, sf, _ = grads["reference_order"]
+    op, of = b["grad_pointcloud"], b["grad_pointcloud_features"]
     # SH columns are left out of the float64 comparison: the restatement evaluates the colour with the forward's ray origin,
     # the reference's backward with t_pointcloud_camera (RAST:731-732), which differ for the non-unit pose quaternion used here
-    for name, a_hip, a_orc, a_f64 in [("xyz", gp, op, ref_pc), ("q", gf[:, 0:4], of[:, 0:4], ref_ft[:, 0:4]),
-                                      ("s", gf[:, 4:7], of[:, 4:7], ref_ft[:, 4:7]), ("opacity", gf[:, 7:8], of[:, 7:8], ref_ft[:, 7:8])]:
-        r = {"hip_vs_oracle": P.rel_err(a_hip, a_orc), "hip_vs_float64": P.rel_err(a_hip, a_f64), "oracle_vs_float64": P.rel_err(a_orc, a_f64)}
+    for name, a_hip, a_strict, a_orc, a_f64 in [("xyz", gp, sp, op, ref_pc), ("q", gf[:, 0:4], sf[:, 0:4], of[:, 0:4], ref_ft[:, 0:4]),
+                                                ("s", gf[:, 4:7], sf[:, 4:7], of[:, 4:7], ref_ft[:, 4:7]),
+                                                ("opacity", gf[:, 7:8], sf[:, 7:8], of[:, 7:8], ref_ft[:, 7:8])]:
+        r = {"fast_vs_oracle": P.rel_err(a_hip, a_orc), "reference_order_vs_oracle": P.rel_err(a_strict, a_orc),
+             "fast_vs_float64": P.rel_err(a_hip, a_f64), "oracle_vs_float64": P.rel_err(a_orc, a_f64)}
         report[name] = r
-        assert r["hip_vs_float64"] < hip_f64_tol, (name, r)            # the HIP result against exact arithmetic
+        assert r["reference_order_vs_oracle"] < 1e-5, (name, r)        # the gap is the operation order of UTIL:343-345 and nothing else
+        assert r["fast_vs_float64"] < hip_f64_tol, (name, r)           # the default form against exact arithmetic
         assert r["oracle_vs_float64"] < orc_f64_tol, (name, r)         # the reference's f32 operation order against it
-    # the signature of an oracle-limited case: HIP is several times closer to float64 than to the oracle, and the oracle is as far
-    # from float64 as it is from HIP (the HIP-oracle gap itself sits at the 1e-4 bar: 1.05e-4 and 1.14e-4 when this was written)
-    # (checked on the column group with the widest HIP-oracle gap: the scales in round 1's two scenes, the rotation in the third,
-    # seed 141447, which round 2's last soak of 2400 scenes turned up: 1.3e-4 on q)
-    worst = max(("xyz", "q", "s", "opacity"), key=lambda n: report[n]["hip_vs_oracle"])
+    worst = max(("xyz", "q", "s", "opacity"), key=lambda n: report[n]["fast_vs_oracle"])
     report["widest_gap_in"] = worst
-    assert report[worst]["hip_vs_oracle"] > closer * report[worst]["hip_vs_float64"]
-    assert report[worst]["oracle_vs_float64"] > 0.7 * report[worst]["hip_vs_oracle"]
+    assert report[worst]["fast_vs_oracle"] > 8e-5                        # the documented gap is really there in the default form
+    assert report[worst]["fast_vs_oracle"] > closer * report[worst]["fast_vs_float64"]
+    assert report[worst]["oracle_vs_float64"] > 0.7 * report[worst]["fast_vs_oracle"]
     report["per_element_bar_use_vs_oracle"] = {k: v["bar_use_max"] for k, v in b["margins"].items()}
     os.makedirs(os.path.join(P.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(P.ROOT, "gpurun_out", f"soak_seed_{seed}.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report))
+
+
+def test_reference_order_backward_at_cfg2(P):
+    """gs_config.bwd_reference_order on a BASELINE-sized frame (config 2): the same bars as the default form, and the two forms
+    agree with each other far inside them."""
+    s = synth(**CONFIGS["cfg2_truck7k"])
+    q, t = view_pose()
+    res = {}
+    for strict in (False, True):
+        cfg = P.Rast.GaussianPointCloudRasterisationConfig()
+        cfg.backward_reference_order = strict
+        module = P.Rast(cfg)
+        inp = P.make_input(s, q, t, 3)
+        image = module(inp)[0]
+        g = 2.0 * (image.detach() - 0.5)
+        image.backward(g)
+        res[strict] = (inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy())
+        if strict:
+            f, _ = P.run_oracle(s, q, t)
+            P.assert_backward_parity(module, inp, g.cpu().numpy(), f, 3)
+    assert P.rel_err(res[True][0], res[False][0]) < 1e-5 and P.rel_err(res[True][1], res[False][1]) < 1e-5
+
+
+def test_predicted_sizing_and_its_redo_change_nothing(P):
+    """The forward queues binning, sort and blend on PREDICTED sizes (what the last frame of the context needed + 25 %) and reads
+    the frame's counters only after its last launch (gs_api.hip: run_forward_tail).  A frame whose prediction held, a frame
+    whose pair count outgrew the prediction (the scene doubles between two frames) and a frame whose depth codes got wider
+    (depth_to_sort_key_scale x 64) must all give, bit for bit, what a fresh context gives with exact sizes -- forward outputs,
+    every exported intermediate, gradients."""
+    q, t = view_pose()
+    small, big = synth(6000, 256, 192, 0.05, seed=41), synth(12000, 256, 192, 0.07, seed=42)
+
+    def run(module, scene):
+        inp = P.make_input(scene, q, t)
+        img, depth, count = module(inp)
+        fr = module.last_frame
+        exports = {n: fr.export(n).cpu().numpy() for n in ("sort_key", "point_offset_with_sort_key", "tile_points_start", "tile_points_end")}
+        (img * img).sum().backward()
+        outs = [x.detach().cpu().numpy().copy() for x in (img, depth, count, inp.point_cloud.grad, inp.point_cloud_features.grad)]
+        return fr.sizing, outs, exports
+
+    def same(a, b):
+        for x, y in zip(a[1], b[1]):
+            assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+        for n in a[2]:
+            assert np.array_equal(a[2][n], b[2][n]), n
+
+    fresh_small = run(P.Rast(P.Rast.GaussianPointCloudRasterisationConfig()), small)
+    fresh_big = run(P.Rast(P.Rast.GaussianPointCloudRasterisationConfig()), big)
+    assert fresh_small[0] == "exact" and fresh_big[0] == "exact"          # first frame of a context: nothing to predict from
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+    first = run(module, small)
+    second = run(module, small)
+    third = run(module, small)
+    assert (first[0], second[0], third[0]) == ("exact", "predicted", "predicted"), (first[0], second[0], third[0])
+    same(second, fresh_small); same(third, fresh_small)
+    grown = run(module, big)                                               # twice the points: the pair count leaves the prediction
+    assert grown[0] == "redone", grown[0]
+    same(grown, fresh_big)
+    again = run(module, big)
+    same(again, fresh_big)
+    # wider depth codes on the same context and image size: the key field of the prediction is too narrow
+    wide_cfg = P.Rast.GaussianPointCloudRasterisationConfig(depth_to_sort_key_scale=6400.0)
+    fresh_wide = run(P.Rast(wide_cfg), big)
+    module.config = wide_cfg
+    wide = run(module, big)
+    assert wide[0] == "redone", wide[0]
+    same(wide, fresh_wide)
+    back = run(module, big)                                                # and a prediction made from the wide frame holds
+    assert back[0] == "predicted", back[0]
+    same(back, fresh_wide)

@@ -5,5 +5,5 @@ for r in 1 2; do for v in "$@"; do GSRAST_LIB=$PWD/build_ab/libgsrast_$v.so pyth
 python - "$tag" <<'PY'
 import json,glob,sys
 for f in sorted(glob.glob("gpurun_out/%s/*.json" % sys.argv[1])):
-    d=json.load(open(f)); k=d["kernels_ms_per_step"]; print(f.split("/")[-1], d["value"], k.get("k_blend_fwd"), k.get("k_blend_bwd_tile"), k.get("k_sum_rows"), k.get("k_project"))
+    d=json.load(open(f)); k=d.get("kernels_ms_per_view") or d["kernels_ms_per_step"]; print(f.split("/")[-1], d["value"], k.get("k_blend_fwd"), k.get("k_blend_bwd_tile"), k.get("k_sum_rows"), k.get("k_project"))
 PY

@@ -1,7 +1,9 @@
 """Host-side cost of one fwd+bwd step against the GPU time of the same step (diagnostic).
 
-The forward hands M and K to the host once per frame, so the host can never run more than the rest of a step ahead
-of the GPU; if the Python + launch work of a step takes longer than that, the GPU idles at the step boundary."""
+The forward hands M and K to the host once per frame.  With predicted sizing (default) the host reads them AFTER it has queued
+the whole forward, so the wait costs the GPU nothing; with GS_PREDICT_SIZES=0 it waits in the middle of the frame with the GPU
+idle behind it.  Prints, per step: host time inside forward / loss / backward, the time spent waiting for the counters
+(gs_ctx_counter_wait_ns) and how each frame was sized.  Run it once with and once without GS_PREDICT_SIZES=0."""
 import os
 import sys
 import time
@@ -40,19 +42,29 @@ def main():
         d = time.perf_counter()
         marks["fwd"] += b - a; marks["loss"] += c - b; marks["bwd"] += d - c
 
+    from taichi_3d_gaussian_splatting_amd import _native
     for _ in range(30):
         step()
     torch.cuda.synchronize()
     for k in marks:
         marks[k] = 0.0
     n = 200
+    L = _native.lib()
+    ctx = module._ctx_for(dev)
+    w0 = L.gs_ctx_counter_wait_ns(ctx)
+    sizing = {}
     t0 = time.perf_counter()
     for _ in range(n):
         step()
+        sizing[module.last_frame.sizing] = sizing.get(module.last_frame.sizing, 0) + 1
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"host loop {1e6 * (t1 - t0) / n:.1f} us/step, with final sync {1e6 * (t2 - t0) / n:.1f} us/step")
+    wait_us = (L.gs_ctx_counter_wait_ns(ctx) - w0) / 1e3 / n
+    print(f"GS_PREDICT_SIZES={os.environ.get('GS_PREDICT_SIZES', '1')}: frames sized {sizing}")
+    print(f"host loop {1e6 * (t1 - t0) / n:.1f} us/step, with final sync {1e6 * (t2 - t0) / n:.1f} us/step; "
+          f"waiting for the frame counters {wait_us:.1f} us/step "
+          f"({'after the last launch of the forward: the GPU is busy meanwhile' if os.environ.get('GS_PREDICT_SIZES', '1')[:1] != '0' else 'in the middle of the forward: the GPU has nothing queued behind the per-point kernels'})")
     print("host time inside: " + ", ".join(f"{k} {1e6 * v / n:.1f} us" for k, v in marks.items()) +
           "  (fwd includes waiting for the GPU to publish M and K)")
     # the same with the GPU idle in between (host cost alone: nothing to wait for except the prologue kernels)
