@@ -11,11 +11,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Rast, _native  # noqa: E402
-from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.synthetic import make_scene, view_pose  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_headline"
 dev = torch.device("cuda", 0)
-s = synth(**CONFIGS[wl]); q, t = view_pose()
+s = make_scene(wl); q, t = view_pose()
 pc = torch.tensor(s.point_cloud, device=dev, requires_grad=True); feat = torch.tensor(s.point_cloud_features, device=dev, requires_grad=True)
 inp = Rast.GaussianPointCloudRasterisationInput(
     point_cloud=pc, point_cloud_features=feat, point_object_id=torch.tensor(s.point_object_id, device=dev),
@@ -29,6 +29,8 @@ for _ in range(3):
     image.backward(2.0 * (image.detach() - 0.5))
 torch.cuda.synchronize()
 T = ((s.height + 15) // 16) * ((s.width + 15) // 16)
+G = int(os.environ.get("GS_BWD_WAVES_PER_TILE", 0)) or (4 if T < 2000 else 2 if T < 6144 else 1)     # gs_api.hip: waves_per_tile
+T = min(T * G, 65536)                                                                                # one record per wave
 buf = (C.c_ulonglong * (2 * T))()
 _native.lib().gs_debug_wave_times_read(buf, T)
 a = np.array(buf, dtype=np.uint64).reshape(T, 2).astype(np.int64)
@@ -36,6 +38,7 @@ t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0).astype(float), (a[:, 1] - t0).astype(float)      # wall-clock ticks (only ratios are used)
 dur = en - st
 span = en.max()
+print(f"{wl}: {G} wave(s) per tile; longest wave / launch span = {dur.max() / span:.3f}")
 print(f"{T} waves, launch span {span:.1f} ticks; wave duration mean {dur.mean():.1f} us, max {dur.max():.1f}, p99 {np.percentile(dur, 99):.1f}, min {dur.min():.1f}")
 print(f"sum of wave durations / (span * 5120 slots) = {dur.sum() / (span * 5120):.3f}")
 for frac in (0.25, 0.5, 0.75, 0.9, 1.0):

@@ -10,11 +10,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Rast, _native  # noqa: E402
-from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.synthetic import make_scene, view_pose  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_headline"
 dev = torch.device("cuda", 0)
-s = synth(**CONFIGS[wl]); q, t = view_pose()
+s = make_scene(wl); q, t = view_pose()
 inp = Rast.GaussianPointCloudRasterisationInput(
     point_cloud=torch.tensor(s.point_cloud, device=dev), point_cloud_features=torch.tensor(s.point_cloud_features, device=dev),
     point_object_id=torch.tensor(s.point_object_id, device=dev), point_invalid_mask=torch.tensor(s.point_invalid_mask, device=dev),
