@@ -217,6 +217,10 @@ int gs_backward(gs_ctx* ctx, gs_frame* frame, const gs_scene* scene, const gs_ca
 
 /* May be called any number of times between forward and release (backward(retain_graph=True) in PyTorch terms). */
 
+/* Diagnostic: how many tiles the last backward blend of this frame treated as HEAVY (a workgroup of four cooperating waves
+ * instead of one wave; k_backward.hip).  Scheduling only -- results do not depend on it.  Synchronises the stream. */
+int gs_frame_heavy_tiles(gs_ctx* ctx, const gs_frame* frame, int32_t* n_out, gs_stream stream);
+
 int gs_frame_release(gs_ctx* ctx, gs_frame* frame);
 
 /* ---- the same path cut at the projected records and at the per-splat sums -----------------

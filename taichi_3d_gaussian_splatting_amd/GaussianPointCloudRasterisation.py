@@ -110,6 +110,13 @@ class _Frame:
             _native.check(L.gs_frame_export(self._context.handle, self.handle, eid, _ptr(out), C.c_void_p(stream)), f"gs_frame_export({name})")
         return out
 
+    def heavy_tiles(self) -> int:
+        """Diagnostic: tiles the last backward blend of this frame shared among four waves (gs_frame_heavy_tiles)."""
+        n = C.c_int32(0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(_native.lib().gs_frame_heavy_tiles(self._context.handle, self.handle, C.byref(n), C.c_void_p(stream)), "gs_frame_heavy_tiles")
+        return int(n.value)
+
     def release(self):
         """Hands the ticket back.  Transient frames (forward without gradient tracking) belong to the context and are
         recycled by its next forward; their ticket then simply stops resolving."""

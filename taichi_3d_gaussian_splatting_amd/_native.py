@@ -87,7 +87,7 @@ EXPORTS = {
 
 # every symbol include/gs_rasterizer.h declares
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
-           "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release",
+           "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release", "gs_frame_heavy_tiles",
            "gs_ctx_device_bytes", "gs_ctx_counter_wait_ns", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
            "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
            "gs_project_shard", "gs_project_shard_begin", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
@@ -158,6 +158,7 @@ def lib():
     L.gs_backward.argtypes = [_VP, _VP, C.POINTER(GsScene), C.POINTER(GsCamera), C.POINTER(GsConfig),
                               _VP, _VP, _VP, _I32, C.POINTER(GsBackwardOut), _VP]
     L.gs_frame_release.argtypes = [_VP, _VP]
+    L.gs_frame_heavy_tiles.argtypes = [_VP, _VP, C.POINTER(_I32), _VP]
     L.gs_ctx_device_bytes.argtypes = [_VP]
     L.gs_profile_enable.argtypes = [_VP, C.c_uint64]
     L.gs_loss_l1_ssim.argtypes = [_VP, _VP, _VP, _I32, _I32, _F32, _VP, _VP, _VP]

@@ -403,7 +403,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     ENSURE(B.rec, 64 * Np);
     ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.depth_codes, 4 * Np); ENSURE(B.offsets, 4 * Np);
     ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared together
-    ENSURE(B.tile_order, 4 * (size_t)T);
+    ENSURE(B.tile_order, 4 * ((size_t)T + 4));     // + the number of heavy tiles behind the order
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
     ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
     ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
@@ -685,7 +685,7 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     const size_t Mp = (size_t)(m > 0 ? m : 1);
     const size_t nb = (size_t)((m + 255) / 256);
     ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.depth_codes, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
-    ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * (size_t)T);
+    ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * ((size_t)T + 4));
     ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
     if (m > 0) HIP_TRY_F(hipMemcpyAsync(B.rec.p, records, (size_t)m * 64, hipMemcpyDeviceToDevice, s));   // the frame keeps its own copy for backward
     GsProjectArgs pa{};
@@ -836,6 +836,9 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.partial = c->partial.as<float>();
     a.visited = c->visited.as<uint8_t>();
     a.G = G;
+    a.n_heavy = B.tile_order.as<int32_t>() + f->info.n_tiles;
+    static const bool split_heavy = []{ const char* e = getenv("GS_BWD_SPLIT_HEAVY"); return !(e && e[0] == '0'); }();
+    a.split_heavy = split_heavy ? 1 : 0;
     a.strict = strict ? 1 : 0;
     a.visited_bytes = flag_bytes + 64 + Mp;
     a.touched = c->visited.as<uint8_t>() + flag_bytes + 64;
@@ -1020,6 +1023,21 @@ extern "C" int gs_adam_step(gs_ctx* c, float* param, const float* grad, float* e
     HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
     gs_launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, reinterpret_cast<hipStream_t>(stream_));
     HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_frame_heavy_tiles(gs_ctx* c, const gs_frame* h, int32_t* n_out, gs_stream stream_)
+{
+    if (!c || !n_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_frame_heavy_tiles: NULL argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    Frame* f = resolve(c, h);
+    if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_heavy_tiles: not a live frame of this context");
+    if (!(f->info.stages & GS_STAGE_RASTER) || f->info.n_tiles <= 0 || !f->bufs->tile_order.p) { *n_out = 0; return GS_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(enter_stream(c, s));
+    HIP_TRY(hipMemcpyAsync(n_out, f->bufs->tile_order.as<int32_t>() + f->info.n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return GS_OK;
 }
 

@@ -15,10 +15,16 @@
 // goes through v_cndmask + v_cmp_ne, two half-rate VALU instructions per vote.
 #define gs_ballot(pred) __builtin_amdgcn_ballot_w64(pred)
 
-// Diagnostic build only (`make stats` -> libgsrast_stats.so, tools/blend_stats.py): event counters of the two blend kernels.
+// Diagnostic builds only, never loaded by the product:
+//   `make stats` (-DGS_STATS=2) -> libgsrast_stats.so: event counters of the two blend kernels (tools/blend_stats.py) + wave times;
+//   `make times` (-DGS_STATS=1) -> libgsrast_times.so: start / end time of every blend wave ONLY (tools/*_wave_timeline.py).
+// The counters are global atomics in the inner loops (~100 ns each on this part): a build that counts runs tens of times
+// slower and its wave times say nothing about the real launch, hence the separate timing-only build.
 #ifdef GS_STATS
 extern __device__ unsigned long long gs_stats_counters[32];
-extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start, end (wall clock ticks) of each k_blend_bwd_tile wave
+extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start, end (wall clock ticks) of each blend wave
+#endif
+#if defined(GS_STATS) && GS_STATS >= 2
 #define GS_STAT(i, n) do { const unsigned long long gs_stat_n = (unsigned long long)(n); if (threadIdx.x % 64 == 0) atomicAdd(&gs_stats_counters[i], gs_stat_n); } while (0)
 #else
 #define GS_STAT(i, n) do { } while (0)
@@ -264,6 +270,8 @@ struct GsBackwardArgs {
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;
     int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
+    int32_t* n_heavy;               // device: number of heavy tiles at the head of tile_order (k_tile_order -> k_blend_bwd_tile)
+    int split_heavy;                // 0: no tile is treated as heavy (GS_BWD_SPLIT_HEAVY=0)
     int strict;                     // gs_config.bwd_reference_order: loop 1's UTIL:331-348 in the reference's own operation order
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
     uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward

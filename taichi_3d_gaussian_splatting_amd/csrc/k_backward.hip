@@ -39,11 +39,21 @@
 // not depend on it.  Work = the (splat, quadrant) evaluations the forward counted for the tile.
 #define ORDER_BINS 2048
 #define ORDER_BIN_WIDTH 4
+// HEAVY tiles: the first n_heavy entries of the order -- tiles whose work is at least HEAVY_FACTOR times the mean and at
+// least HEAVY_MIN_WORK evaluations (at most T / 8 of them, HEAVY_CAP in all).  k_blend_bwd_tile gives each of them a whole
+// workgroup (four cooperating waves, one per quadrant) instead of one wave: on a clustered scene a few tiles carry lists
+// ten to twenty times the mean and their single waves ARE the launch (profiles/r03_*_wave_timeline*.txt); on the uniform
+// generator (max / mean = 2) there are none.  Scheduling only, like the order itself.
+#define HEAVY_FACTOR 3
+#define HEAVY_MIN_WORK 1024
+#define HEAVY_CAP 1024
+__host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? T / 8 : HEAVY_CAP; }
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,
-                                                     uint4* __restrict__ clear, size_t clear_vec)
+                                                     uint4* __restrict__ clear, size_t clear_vec, int32_t* __restrict__ n_heavy_out, int split_heavy)
 {
     __shared__ uint32_t bins[ORDER_BINS];
     __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long wtot[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (blockIdx.x > 0) {
         // the other workgroups of the launch clear the `visited` flags (and the all-zero row behind them) for the blend
@@ -54,10 +64,16 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     }
     for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
     __syncthreads();
+    unsigned long long total = 0ull;
     for (int i = t; i < T; i += 1024) {
-        int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+        const int work = tile_work[i];
+        total += (unsigned long long)(work > 0 ? work : 0);
+        int w = work / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
         atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);               // bin 0 = heaviest
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (lane == 0) wtot[wave] = total;
     __syncthreads();
     // exclusive scan of the 2048 bins (2 per thread)
     uint32_t a = bins[2 * t], b = bins[2 * t + 1];
@@ -71,6 +87,21 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     const uint32_t excl = woff + incl - (a + b);
     __syncthreads();
     bins[2 * t] = excl; bins[2 * t + 1] = excl + a;
+    __syncthreads();
+    if (t == 0) {
+        // tiles in bins of work >= thr: bin index < ORDER_BINS - thr / width; their number = the scanned start of the first bin below
+        unsigned long long sum = 0ull;
+        for (int w = 0; w < 16; ++w) sum += wtot[w];
+        const unsigned long long mean = T > 0 ? sum / (unsigned long long)T : 0ull;
+        unsigned long long thr = HEAVY_FACTOR * mean;
+        if (thr < HEAVY_MIN_WORK) thr = HEAVY_MIN_WORK;
+        unsigned long long bw = (thr + ORDER_BIN_WIDTH - 1) / ORDER_BIN_WIDTH;              // first bin (by work) that counts as heavy
+        if (bw > ORDER_BINS - 1) bw = ORDER_BINS - 1;                                       // (everything beyond the last bin edge shares it)
+        int n = 0;
+        if (split_heavy) n = (int)bins[ORDER_BINS - (int)bw];                               // start of the heaviest light bin = number of heavier tiles
+        const int cap = gs_heavy_cap(T);
+        *n_heavy_out = n < cap ? n : cap;
+    }
     __syncthreads();
     for (int i = t; i < T; i += 1024) {
         int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
@@ -94,27 +125,29 @@ struct QuadState { float T, W, gr, gg, gb, tot0, tot1; int last; };
 // accurate than the reference's own rounding, which is why three ill-conditioned soak scenes sit 1.05e-4 .. 1.5e-4 of the tensor
 // maximum from the oracle in the fast form and at the summation-order floor in this one
 // (tests/test_gpu_parity.py::test_soak_seeds_with_ill_conditioned_splats, profiles/r03_strict_vs_fast.json).
-template <int NQ, bool STRICT>
-__global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order,
-                                                       const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
-                                                       const int32_t* __restrict__ sorted_vals,
-                                                       const float4* __restrict__ PA, const float4* __restrict__ PB,
-                                                       const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
-                                                       const uint32_t* __restrict__ offsets,
-                                                       const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
-                                                       const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
-                                                       float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
-                                                       float* __restrict__ mag_image)
+// COOP: the wave is one of the FOUR waves of a workgroup that share a HEAVY tile (NQ = 1: a quadrant each).  They walk the
+// list batch by batch in step; a wave leaves the sum of a splat over its own quadrant in its record slab (a processed splat's
+// 48-byte record is dead, and twelve floats is what a row holds), and after the batch the workgroup adds the four slabs up and
+// stores ONE row per pair -- the same rows, flags and per-point sums as the single-wave form, a heavy tile's critical path
+// cut to a quarter of the quadrant evaluations.  (Summation order within a pair: quadrants 0..3, each summed as before.)
+struct BwdCoop { unsigned long long* done; int32_t* slot; int32_t* point; int32_t* tile_last; float (*slab)[64][12]; };
+
+template <int NQ, bool STRICT, bool COOP>
+__device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, const int G_rows, float4 (*sRec)[3], float* sRed, const BwdCoop coop,
+                                                 const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                 const int32_t* __restrict__ sorted_vals,
+                                                 const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                 const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
+                                                 const uint32_t* __restrict__ offsets,
+                                                 const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
+                                                 const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
+                                                 float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
+                                                 float* __restrict__ mag_image)
 {
-    __shared__ float4 sRec[64][3];             // the batch's splat records
-    __shared__ __attribute__((aligned(16))) float sRed[11 * RED_STRIDE];
-    constexpr int G = 4 / NQ;
-    const int tile = tile_order[blockIdx.x / G];
 #ifdef GS_STATS
     const unsigned long long gs_t0 = wall_clock64();
 #endif
-    const int grp = blockIdx.x % G;               // which NQ quadrants of the tile this wave owns
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
     const int start = tile_start[tile], end = tile_end[tile];
     const int lx = lane & 7, ly = lane >> 3;
@@ -140,6 +173,11 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
     int tile_last = qlast[0];
 #pragma unroll
     for (int qi = 1; qi < NQ; ++qi) tile_last = max(tile_last, qlast[qi]);
+    if constexpr (COOP) {                        // the four waves walk the same batches: the tile's last index over all of them
+        if (lane == 0) coop.tile_last[grp] = tile_last;
+        __syncthreads();
+        tile_last = max(max(coop.tile_last[0], coop.tile_last[1]), max(coop.tile_last[2], coop.tile_last[3]));
+    }
     bool pixels_finite;                          // every pixel gradient and final T of this wave is a finite number
     {
         float t = 0.0f;
@@ -180,11 +218,14 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) fsum += Q[qi].W;              // (a NaN colour met in an earlier batch lives on in W)
             const bool clean = pixels_finite && gs_ballot(!(fsum - fsum == 0.0f)) == 0ull;
+            unsigned long long done = 0ull;                                   // COOP: splats this wave left a sum for in its slab
             if (U) {
                 uint32_t slot = 0;
                 if ((U >> lane) & 1ull) {                                     // pre-sort slot of this (point, tile) pair
                     const ushort4 bx = boxes[p];
-                    slot = (offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z))) * G + grp;
+                    slot = (offsets[p] + (uint32_t)(((int)bx.w - (int)bx.z) * (tile_u - (int)bx.x) + (tile_v - (int)bx.z))) * (uint32_t)G_rows
+                           + (COOP ? 0u : (uint32_t)grp);
+                    if constexpr (COOP) { coop.slot[lane] = (int32_t)slot; coop.point[lane] = p; }   // (every wave that keeps the splat writes the same two values)
                 }
                 sRec[lane][0] = A; sRec[lane][1] = B; sRec[lane][2] = C;
                 __builtin_amdgcn_wave_barrier();
@@ -323,23 +364,59 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
                     t += gs_dpp<0xB1>(t);              // quad_perm [1,0,3,2]
                     t += gs_dpp<0x4E>(t);              // quad_perm [2,3,0,1]
                     if (lane == 40) t = __int_as_float(n_use);      // the count travels as an integer end to end (exact for any image size)
-                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-                    float* row = partial + (size_t)sj * PW;
-                    if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
-                    if (lane == 63) { visited[sj] = 1; touched[__builtin_amdgcn_readlane(p, j)] = 1; }   // row written; point has a contribution
+                    if constexpr (COOP) {
+                        // the splat's record has been consumed: its 48 bytes of the slab take this quadrant's twelve sums
+                        if ((lane & 3) == 0 && lane < 48) reinterpret_cast<float*>(&sRec[j][0])[lane >> 2] = t;
+                        done |= 1ull << j;
+                    } else {
+                        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+                        float* row = partial + (size_t)sj * PW;
+                        if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
+                        if (lane == 63) { visited[sj] = 1; touched[__builtin_amdgcn_readlane(p, j)] = 1; }   // row written; point has a contribution
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            if constexpr (COOP) {
+                // the workgroup adds its four slabs up: thread (j, part) takes floats 3 part .. 3 part + 2 of splat j, quadrants in
+                // order 0..3 (column 10, the contribution count, as the integer it is), and stores the pair's row
+                if (lane == 0) coop.done[grp] = done;
+                __syncthreads();
+                const int tj = (int)(threadIdx.x >> 2), part = (int)(threadIdx.x & 3);
+                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+                int cnt = 0;
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if ((coop.done[w] >> tj) & 1ull) {
+                        const float* src = &coop.slab[w][tj][3 * part];
+                        r0 += src[0];
+                        if (part == 3) cnt += __float_as_int(src[1]);                       // column 10: an integer
+                        else { r1 += src[1]; r2 += src[2]; }
+                        any = true;
+                    }
+                }
+                if (any) {
+                    const uint32_t sj = (uint32_t)coop.slot[tj];
+                    float* row = partial + (size_t)sj * PW + 3 * part;
+                    row[0] = r0; row[1] = part == 3 ? __int_as_float(cnt) : r1; row[2] = r2;      // (column 11 is padding: 0)
+                    if (part == 0) { visited[sj] = 1; touched[coop.point[tj]] = 1; }
+                }
+                __syncthreads();                                                            // the slabs are free for the next batch
+            }
         }
     }
 #ifdef GS_STATS
-    if (lane == 0 && blockIdx.x < 65536) { gs_stats_wave_times[2 * blockIdx.x] = gs_t0; gs_stats_wave_times[2 * blockIdx.x + 1] = wall_clock64(); }
+    {
+        const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+        if (lane == 0 && wid < 65536u) { gs_stats_wave_times[2 * wid] = gs_t0; gs_stats_wave_times[2 * wid + 1] = wall_clock64(); }
+    }
 #endif
     if (mag_image) {                                                            // RAST:700-704
         // pixel coordinates derived afresh (the asm hides that they equal the prologue's): five registers would otherwise stay
         // live across the whole walk, and the kernel sits exactly at the 96-VGPR boundary of five waves per SIMD
-        int lane_e = threadIdx.x;
+        int lane_e = threadIdx.x & 63;
         asm volatile("" : "+v"(lane_e));
         const int lx_e = lane_e & 7, ly_e = lane_e >> 3;
 #pragma unroll
@@ -351,6 +428,45 @@ __global__ __launch_bounds__(64, 4) void k_blend_bwd_tile(const int32_t* __restr
             mag_image[2 * o] = Q[qi].tot0; mag_image[2 * o + 1] = Q[qi].tot1;
         }
     }
+}
+
+// One launch for the whole backward blend.  Workgroups of four waves: the first *n_heavy workgroups take one HEAVY tile each
+// (k_tile_order put those at the head of the order) and share it cooperatively, a quadrant per wave; every later workgroup
+// takes four (tile, quadrant group) work items of the ordinary kind -- NQ = 4: four tiles, one wave each; NQ = 2: two tiles,
+// two waves each; NQ = 1: one tile.  The grid is sized for the largest possible number of heavy tiles (the host does not know
+// n_heavy); surplus workgroups leave at once.
+template <int NQ, bool STRICT>
+__global__ __launch_bounds__(256, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order, const int32_t* __restrict__ n_heavy_ptr, int T,
+                                                        const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                        const int32_t* __restrict__ sorted_vals,
+                                                        const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                        const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
+                                                        const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
+                                                        float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
+                                                        float* __restrict__ mag_image)
+{
+    __shared__ float4 sRecAll[4][64][3];             // per wave: the batch's splat records (COOP: then the per-quadrant sums)
+    __shared__ __attribute__((aligned(16))) float sRedAll[4][11 * RED_STRIDE];
+    __shared__ unsigned long long sDone[4];
+    __shared__ int32_t sSlot[64], sPoint[64], sTileLast[4];
+    constexpr int G = 4 / NQ;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_heavy = *n_heavy_ptr;
+    BwdCoop coop;
+    coop.done = sDone; coop.slot = sSlot; coop.point = sPoint; coop.tile_last = sTileLast;
+    coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
+    if ((int)blockIdx.x < n_heavy) {
+        gs_bwd_tile_body<1, STRICT, true>(tile_order[blockIdx.x], wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
+                                          PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, mag_image);
+        return;
+    }
+    const int item = ((int)blockIdx.x - n_heavy) * 4 + wave;          // work item among the ordinary (tile, quadrant group) pairs
+    const int ti = n_heavy + item / G;
+    if (ti >= T) return;
+    gs_bwd_tile_body<NQ, STRICT, false>(tile_order[ti], item % G, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
+                                        PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, mag_image);
 }
 
 // ---------------------------------------------------------------------------------
@@ -717,14 +833,16 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         const size_t clear_vec = (a.visited_bytes + 15) / 16;
         const unsigned clear_groups = (unsigned)((clear_vec + 4095) / 4096 < 1024 ? (clear_vec + 4095) / 4096 : 1024);
         GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint,
-                                                                                         reinterpret_cast<uint4*>(a.visited), clear_vec));
-#define GS_BWD_LAUNCH(NQ_, STRICT_, WAVES_)                                                                                           \
-        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<(WAVES_), 64, 0, s>>>(a.tile_order, a.tile_start, a.tile_end,   \
-                 a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x, a.partial,      \
-                 a.visited, a.touched, a.mag_image))
-        if (a.G == 1) { if (a.strict) GS_BWD_LAUNCH(4, true, a.T); else GS_BWD_LAUNCH(4, false, a.T); }
-        else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true, a.T * 2); else GS_BWD_LAUNCH(2, false, a.T * 2); }
-        else { if (a.strict) GS_BWD_LAUNCH(1, true, a.T * 4); else GS_BWD_LAUNCH(1, false, a.T * 4); }
+                                                                                         reinterpret_cast<uint4*>(a.visited), clear_vec, a.n_heavy, a.split_heavy));
+        // workgroups: at most gs_heavy_cap(T) heavy tiles + the ordinary work items four to a workgroup
+        const unsigned groups = (unsigned)gs_heavy_cap(a.T) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
+#define GS_BWD_LAUNCH(NQ_, STRICT_)                                                                                                    \
+        GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<groups, 256, 0, s>>>(a.tile_order, a.n_heavy, a.T, a.tile_start,  \
+                 a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x,   \
+                 a.partial, a.visited, a.touched, a.mag_image))
+        if (a.G == 1) { if (a.strict) GS_BWD_LAUNCH(4, true); else GS_BWD_LAUNCH(4, false); }
+        else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true); else GS_BWD_LAUNCH(2, false); }
+        else { if (a.strict) GS_BWD_LAUNCH(1, true); else GS_BWD_LAUNCH(1, false); }
 #undef GS_BWD_LAUNCH
     }
     else if (a.mag_image)

@@ -655,3 +655,18 @@ def test_predicted_sizing_and_its_redo_change_nothing(P):
     back = run(module, big)                                                # and a prediction made from the wide frame holds
     assert back[0] == "predicted", back[0]
     same(back, fresh_wide)
+
+
+def test_heavy_tiles_shared_by_four_waves_clustered_scene(P):
+    """A heavy-tailed scene (synthetic.synth_clustered: an object that fills a tenth of the image with translucent splats, a
+    sparse shell, a few huge floaters): the tiles whose work is three times the mean or more get a whole workgroup in the backward
+    blend -- four waves, a quadrant each, their per-splat sums added up in LDS before the pair's one row is stored
+    (k_backward.hip: COOP).  Same bars against the oracle as everywhere; and the count of such tiles is not zero here."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import synth_clustered
+    for (n, w, h), waves in (((40000, 480, 272), "four waves per ordinary tile"), ((150000, 1600, 1024), "one wave per ordinary tile")):
+        s = synth_clustered(n, w, h, 0.02, sh_deg=3, seed=3)
+        q, t = view_pose(2, 8)
+        module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=9)
+        lens = f.tile_points_end - f.tile_points_start
+        assert lens.max() > 8 * lens.mean(), (lens.max(), lens.mean())
+        assert module.last_frame.heavy_tiles() > 0, waves

@@ -16,13 +16,13 @@ os.environ.setdefault("GSRAST_LIB", os.path.join(os.path.dirname(os.path.dirname
 import torch  # noqa: E402
 
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Rast, _native  # noqa: E402
-from taichi_3d_gaussian_splatting_amd.synthetic import CONFIGS, synth, view_pose  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.synthetic import make_scene, view_pose  # noqa: E402
 
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_headline"
     dev = torch.device("cuda", 0)
-    s = synth(**CONFIGS[wl])
+    s = make_scene(wl)
     q, t = view_pose()
     pc = torch.tensor(s.point_cloud, device=dev, requires_grad=True)
     feat = torch.tensor(s.point_cloud_features, device=dev, requires_grad=True)

@@ -1,12 +1,13 @@
 """Start/end time of every k_blend_bwd_tile wave of one backward (stats build): wave durations and how many waves are
-resident over the launch, i.e. how much of the launch is tail.  `make -C taichi_3d_gaussian_splatting_amd/csrc stats` first."""
+resident over the launch, i.e. how much of the launch is tail.  `make -C taichi_3d_gaussian_splatting_amd/csrc times` first (the timing-only diagnostic build: the counting build's
+atomics make every wave tens of times slower)."""
 import ctypes as C
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GSRAST_LIB", os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "lib", "libgsrast_stats.so"))
+os.environ.setdefault("GSRAST_LIB", os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "lib", "libgsrast_times.so"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -30,16 +31,22 @@ for _ in range(3):
 torch.cuda.synchronize()
 T = ((s.height + 15) // 16) * ((s.width + 15) // 16)
 G = int(os.environ.get("GS_BWD_WAVES_PER_TILE", 0)) or (4 if T < 2000 else 2 if T < 6144 else 1)     # gs_api.hip: waves_per_tile
-T = min(T * G, 65536)                                                                                # one record per wave
-buf = (C.c_ulonglong * (2 * T))()
-_native.lib().gs_debug_wave_times_read(buf, T)
-a = np.array(buf, dtype=np.uint64).reshape(T, 2).astype(np.int64)
+n_heavy = module.last_frame.heavy_tiles()
+# one record per wave, indexed by workgroup * 4 + wave: the heavy tiles' workgroups first, then the ordinary work items four
+# to a workgroup (k_backward.hip: k_blend_bwd_tile)
+nrec = min(4 * (n_heavy + (T * G - n_heavy * G + 3) // 4), 65536)
+buf = (C.c_ulonglong * (2 * nrec))()
+_native.lib().gs_debug_wave_times_read(buf, nrec)
+a = np.array(buf, dtype=np.uint64).reshape(nrec, 2).astype(np.int64)
+a = a[a[:, 1] > a[:, 0]]
+T = a.shape[0]
+print(f"{wl}: {n_heavy} heavy tiles (4 cooperating waves each), {G} wave(s) per ordinary tile")
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0).astype(float), (a[:, 1] - t0).astype(float)      # wall-clock ticks (only ratios are used)
 dur = en - st
 span = en.max()
 print(f"{wl}: {G} wave(s) per tile; longest wave / launch span = {dur.max() / span:.3f}")
-print(f"{T} waves, launch span {span:.1f} ticks; wave duration mean {dur.mean():.1f} us, max {dur.max():.1f}, p99 {np.percentile(dur, 99):.1f}, min {dur.min():.1f}")
+print(f"{T} waves, launch span {span:.0f} ticks of the 100 MHz wall clock = {span / 100:.1f} us; wave duration mean {dur.mean() / 100:.1f} us, max {dur.max() / 100:.1f}, p99 {np.percentile(dur, 99) / 100:.1f}, min {dur.min() / 100:.1f}")
 print(f"sum of wave durations / (span * 5120 slots) = {dur.sum() / (span * 5120):.3f}")
 for frac in (0.25, 0.5, 0.75, 0.9, 1.0):
     tt = span * frac - 1e-6
