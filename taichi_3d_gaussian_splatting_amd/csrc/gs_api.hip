@@ -120,7 +120,8 @@ struct gs_ctx {
     std::vector<Frame*> frames;         // slot i of the ticket space (recycled, generation-tagged)
     int transient = -1;                 // slot of the frame of the last keep_for_backward == 0 call
     // scratch shared by all frames (stream ordered)
-    DevBuf block_counts, block_offsets, tile_block_sums, tile_block_offsets, hist, scan_tmp, counters, partial, visited, sums, loss_ws;
+    DevBuf block_counts, block_offsets, tile_block_sums, hist, scan_tmp, counters, partial, visited, zero_row, sums, loss_ws;
+    uint8_t visit_gen = 0;                 // tag of the last backward's flags in `visited` (0: the buffer is all zero)
     GsCounters* host_counters = nullptr;   // pinned, device-visible, GS_COUNTER_SLOTS of them; written by k_scan_tiles_publish
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
     uint64_t slots_busy = 1ull;            // slot 0 serves the calls that wait at once; the others belong to frames begun and not yet read
@@ -178,8 +179,8 @@ extern "C" int gs_destroy(gs_ctx* c)
     (void)hipDeviceSynchronize();
     for (FrameBufs* b : c->pool) { b->release(&c->device_bytes); delete b; }
     for (Frame* f : c->frames) delete f;
-    DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->tile_block_offsets, &c->hist, &c->scan_tmp,
-                      &c->counters, &c->partial, &c->visited, &c->sums, &c->loss_ws, &c->order_hint };
+    DevBuf* all[] = { &c->block_counts, &c->block_offsets, &c->tile_block_sums, &c->hist, &c->scan_tmp,
+                      &c->counters, &c->partial, &c->visited, &c->zero_row, &c->sums, &c->loss_ws, &c->order_hint };
     for (DevBuf* b : all) b->release(&c->device_bytes);
     for (GsProf::Rec& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof.spare) (void)hipEventDestroy(e);
@@ -406,7 +407,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     ENSURE(B.tile_order, 4 * ((size_t)T + 4));     // + the number of heavy tiles behind the order
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
     ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
-    ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
+    ENSURE(c->tile_block_sums, 4 * (nb + 1));
 
     GsProjectArgs pa{};
     pa.prof = &c->prof;
@@ -419,7 +420,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.ids = B.ids.as<int32_t>(); pa.cam_index = B.cam_index.as<int32_t>();
     set_records(pa, B, Np);
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
-    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
+    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
     int slot = 0;
@@ -429,7 +430,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     }
     pa.host_mirror = c->host_counters_dev + slot; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
-    gs_launch_project(pa, s);
+    gs_launch_project(pa, s, wait != WAIT_LATER);      // WAIT_LATER: the caller decides who publishes the counters (run_forward_tail)
     HIP_TRY_F(hipGetLastError());
     *pa_out = pa;
     *M_out = 0; *K_out = 0u; *max_code_out = 0;
@@ -446,7 +447,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
 // Both may be PREDICTIONS (run_forward_tail): the kernels take the frame's real pair count from the device counters and stay
 // inside K_bound whatever it is, and any depth_bits >= the real width sorts into the same order.
 static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_t n_rows, int M_bound, uint32_t K_bound, int depth_bits,
-                            int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s)
+                            int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s, bool publish)
 {
     FrameBufs& B = *f->bufs;
     const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
@@ -463,7 +464,8 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     ba.N = n_rows; ba.M = M_bound; ba.K = K_bound; ba.counters = c->counters.as<GsCounters>();
     ba.H = H; ba.W = W; ba.tiles_x = tiles_x; ba.depth_scale = cfg->depth_to_sort_key_scale;
     ba.depth_bits = depth_bits; ba.key_bits = depth_bits + tile_bits;
-    ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.depth_codes = pa.depth_codes; ba.tile_block_offsets = pa.tile_block_offsets;
+    ba.PA = pa.PA; ba.PB = pa.PB; ba.box = pa.box; ba.ntiles = pa.ntiles; ba.depth_codes = pa.depth_codes; ba.tile_block_sums = pa.tile_block_sums;
+    ba.counters_rw = pa.counters; ba.host_mirror = publish ? pa.host_mirror : nullptr; ba.ticket = pa.ticket;   // publish: k_keygen's last block hands the counters over
     ba.block_offsets = pa.block_offsets; ba.block_counts = pa.block_counts;     // NULL for records that did not come from k_project
     ba.offsets = B.offsets.as<uint32_t>();
     ba.keys_a = B.keys_a.p; ba.keys_b = B.keys_b.p; ba.key64 = key64;
@@ -514,7 +516,7 @@ static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     int rc, M = 0, max_code = 0; uint32_t K = 0;
     f->info.sizing = GS_SIZING_EXACT;
     if (n_rows == 0) {                                     // nothing was published: an empty frame
-        if ((rc = run_raster_stage(c, f, pa, 0, 0, 0u, 1, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+        if ((rc = run_raster_stage(c, f, pa, 0, 0, 0u, 1, H, W, tiles_x, T, cfg, out, s, false)) != GS_OK) return rc;
         *M_out = 0; *K_out = 0u;
         return GS_OK;
     }
@@ -524,7 +526,7 @@ static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
         const uint64_t want = (uint64_t)c->seen.K + c->seen.K / 4 + 4096;      // buffers grow to this if they have to (once)
         const uint32_t K_p = (uint32_t)std::min<uint64_t>(want, 0x7fffffffu);
         if (K_p > 0 && bits_p + tile_bits <= 63) {
-            if ((rc = run_raster_stage(c, f, pa, n_rows, M_known >= 0 ? M_known : (int)n_rows, K_p, bits_p, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+            if ((rc = run_raster_stage(c, f, pa, n_rows, M_known >= 0 ? M_known : (int)n_rows, K_p, bits_p, H, W, tiles_x, T, cfg, out, s, true)) != GS_OK) return rc;
             if ((rc = read_counters(c, f, s, ticket, &M, &K, &max_code)) != GS_OK) return rc;
             if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
             const int bits = bits_for((uint32_t)(max_code > 0 ? max_code : 0));
@@ -533,7 +535,7 @@ static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
             } else {
                 // the per-pixel half ran on sizes that did not hold: its results are void (not out of bounds).  Again, exactly.
                 HIP_TRY_F(hipMemsetAsync(pa.tile_arrays, 0, sizeof(int32_t) * (size_t)pa.tile_ints, s));
-                if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits, H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+                if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits, H, W, tiles_x, T, cfg, out, s, false)) != GS_OK) return rc;
                 f->info.sizing = GS_SIZING_REDONE;
             }
             c->seen.valid = true; c->seen.H = H; c->seen.W = W; c->seen.K = K; c->seen.max_code = max_code;
@@ -541,9 +543,11 @@ static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
             return GS_OK;
         }
     }
+    gs_launch_publish(pa, (int)((n_rows + 255) / 256), s);            // exact sizing: the hand-over is a launch of its own, and the host waits for it here
+    HIP_TRY_F(hipGetLastError());
     if ((rc = read_counters(c, f, s, ticket, &M, &K, &max_code)) != GS_OK) return rc;
     if (K >= (1u << 31)) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "more than 2^31 sort pairs (tile ranges are int32, RAST:954-957)"); }
-    if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits_for((uint32_t)(max_code > 0 ? max_code : 0)), H, W, tiles_x, T, cfg, out, s)) != GS_OK) return rc;
+    if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits_for((uint32_t)(max_code > 0 ? max_code : 0)), H, W, tiles_x, T, cfg, out, s, false)) != GS_OK) return rc;
     c->seen.valid = true; c->seen.H = H; c->seen.W = W; c->seen.K = K; c->seen.max_code = max_code;
     *M_out = M; *K_out = K;
     return GS_OK;
@@ -686,18 +690,18 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     const size_t nb = (size_t)((m + 255) / 256);
     ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.depth_codes, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
     ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * ((size_t)T + 4));
-    ENSURE(c->tile_block_sums, 4 * (nb + 1)); ENSURE(c->tile_block_offsets, 4 * (nb + 1));
+    ENSURE(c->tile_block_sums, 4 * (nb + 1));
     if (m > 0) HIP_TRY_F(hipMemcpyAsync(B.rec.p, records, (size_t)m * 64, hipMemcpyDeviceToDevice, s));   // the frame keeps its own copy for backward
     GsProjectArgs pa{};
     pa.prof = &c->prof; pa.N = m; pa.H = H; pa.W = W; pa.depth_scale = cfg->depth_to_sort_key_scale;
     set_records(pa, B, Mp);
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
-    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>(); pa.tile_block_offsets = c->tile_block_offsets.as<uint32_t>();
+    pa.tile_block_sums = c->tile_block_sums.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
     pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
     pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
-    gs_launch_boxes_from_records(pa, (int)m, s);
+    gs_launch_boxes_from_records(pa, (int)m, s, false);       // the counters are published from run_forward_tail
     HIP_TRY_F(hipGetLastError());
     uint32_t K = 0; int M_seen = 0;
     if ((rc = run_forward_tail(c, f, pa, m, (int)m, pa.ticket, H, W, tiles_x, T, cfg, out, s, &M_seen, &K)) != GS_OK) return rc;
@@ -805,7 +809,7 @@ static int waves_per_tile(int n_tiles)
 
 // fills the blend half of the arguments; sums_out = where the per-splat sums go
 static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_image, const float* acc_alpha, const int32_t* last,
-                                  float* mag_image, float4* sums_out, int strict, GsBackwardArgs* a_out)
+                                  float* mag_image, float4* sums_out, int strict, hipStream_t stream, GsBackwardArgs* a_out)
 {
     const uint32_t K = (uint32_t)f->info.n_keys;
     const int G = waves_per_tile(f->info.n_tiles);
@@ -814,8 +818,21 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     hipError_t e = c->partial.ensure(rows * 12 * sizeof(float), &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: partial-sum buffer");
     const size_t Mp = (size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1);
-    e = c->visited.ensure(flag_bytes + 64 + Mp + 16, &c->device_bytes);
+    // Row flags (K*G bytes) and per-point `touched` bytes behind them.  They are TAGGED, not cleared: a backward writes its own tag
+    // (1..255) and reads a flag as set only if it holds that tag, so the 6 MB clear per backward is gone; the buffer is zeroed when it
+    // is (re)allocated and when the tags wrap round.
+    const void* before = c->visited.p;
+    e = c->visited.ensure(flag_bytes + Mp + 16, &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: visited buffer");
+    if (c->visited.p != before || c->visit_gen == 255) {
+        HIP_TRY(hipMemsetAsync(c->visited.p, 0, c->visited.cap, stream));
+        c->visit_gen = 0;
+    }
+    c->visit_gen += 1;
+    if (!c->zero_row.p) {
+        if (c->zero_row.ensure(64, &c->device_bytes) != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "backward: zero row");
+        HIP_TRY(hipMemsetAsync(c->zero_row.p, 0, c->zero_row.cap, stream));
+    }
     if (c->order_hint_T != f->info.n_tiles) {          // another tile grid: the old ordering is void from here on
         c->order_hint_T = 0;
         if (c->order_hint.ensure(4 * (size_t)(f->info.n_tiles > 0 ? f->info.n_tiles : 1), &c->device_bytes) != hipSuccess)
@@ -840,9 +857,9 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     static const bool split_heavy = []{ const char* e = getenv("GS_BWD_SPLIT_HEAVY"); return !(e && e[0] == '0'); }();
     a.split_heavy = split_heavy ? 1 : 0;
     a.strict = strict ? 1 : 0;
-    a.visited_bytes = flag_bytes + 64 + Mp;
-    a.touched = c->visited.as<uint8_t>() + flag_bytes + 64;
-    a.zero_row = reinterpret_cast<const float4*>(c->visited.as<uint8_t>() + flag_bytes);
+    a.gen = c->visit_gen;
+    a.touched = c->visited.as<uint8_t>() + flag_bytes;
+    a.zero_row = c->zero_row.as<float4>();
     a.sums = sums_out;
     a.mag_image = mag_image;
     *a_out = a;
@@ -912,7 +929,7 @@ extern "C" int gs_backward(gs_ctx* c, gs_frame* h, const gs_scene* sc, const gs_
     if (c->sums.ensure((size_t)(f->info.n_points_in_camera > 0 ? f->info.n_points_in_camera : 1) * 48, &c->device_bytes) != hipSuccess)
         return fail(GS_ERR_OUT_OF_MEMORY, "gs_backward: per-point sums buffer");
     GsBackwardArgs a{};
-    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), cfg->bwd_reference_order, &a)) != GS_OK) return rc;
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, out->magnitude_grad_viewspace_on_image, c->sums.as<float4>(), cfg->bwd_reference_order, s, &a)) != GS_OK) return rc;
     if ((rc = prepare_backward_points(f, sc, cam, cfg, sh_band, out, c->sums.as<float4>(), &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
     if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
@@ -938,7 +955,7 @@ extern "C" int gs_backward_projected(gs_ctx* c, gs_frame* h, const float* grad_i
     HIP_TRY(enter_stream(c, s));
     GsBackwardArgs a{};
     int rc;
-    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), f->bwd_reference_order, &a)) != GS_OK) return rc;
+    if ((rc = prepare_backward_blend(c, f, grad_image, acc_alpha, last, mag_image, reinterpret_cast<float4*>(splat_sums_out), f->bwd_reference_order, s, &a)) != GS_OK) return rc;
     gs_launch_backward_blend(a, s);
     if (a.T > 0 && a.K > 0) c->order_hint_T = a.T;          // k_tile_order ran: the hint is a complete permutation
     HIP_TRY(hipGetLastError());

@@ -64,6 +64,23 @@ struct GsCounters {
     int32_t pad[3];
 };
 
+// One thread hands the frame counters to the host (see k_project.hip: k_scan_tiles_publish, k_binning.hip: k_keygen).
+__device__ __forceinline__ void gs_publish_counters(GsCounters* __restrict__ counters, uint32_t K, volatile GsCounters* host_mirror, int32_t ticket)
+{
+    counters->K = K;
+    host_mirror->M = counters->M;
+    host_mirror->K = K;
+    host_mirror->max_depth_code = counters->max_depth_code;
+    host_mirror->bad_object_ids = counters->bad_object_ids;
+    __threadfence_system();
+    host_mirror->reserved = ticket;              // the host waits for this value
+    __threadfence_system();
+    // the accumulating counters start the next frame at zero (zero at gs_create for the first one): no clearing
+    // launch, and no block of the next k_filter / k_project can run ahead of a clear
+    counters->max_depth_code = 0;
+    counters->bad_object_ids = 0;
+}
+
 // ---- device math -------------------------------------------------------------
 __device__ __forceinline__ float gs_expf(float x)
 {
@@ -216,16 +233,17 @@ struct GsProjectArgs {
     int64_t N; const float* q_pc; const float* t_pc; int n_objects; const float* Kmat;
     int H, W; float near_plane, far_plane, depth_scale;
     GsPose* pose; int8_t* mask; int32_t* block_counts; int32_t* block_offsets; int32_t* ids; int32_t* cam_index;
-    float4 *PA, *PB, *PC, *PD; ushort4* box; int32_t* ntiles; uint32_t* tile_block_sums; uint32_t* tile_block_offsets;
+    float4 *PA, *PB, *PC, *PD; ushort4* box; int32_t* ntiles; uint32_t* tile_block_sums;
     int32_t* depth_codes;                       // (M) i32(depth * scale) per in-camera point, for the key build
     GsCounters* counters;
     int32_t* tile_arrays; int tile_ints;        // tile_start | tile_end | tile_work, cleared before the binning
     GsCounters* host_mirror; int32_t ticket;    // pinned host copy of the counters; .reserved = ticket once they are valid
 };
-void gs_launch_project(const GsProjectArgs& a, hipStream_t s);
+void gs_launch_project(const GsProjectArgs& a, hipStream_t s, bool publish);
+void gs_launch_publish(const GsProjectArgs& a, int n_blocks, hipStream_t s);    // the hand-over of the counters as a launch of its own
 // the per-pixel half started from records (gs_forward_projected): tile boxes, counts, block sums and the depth-code range
 // from the records, then the same scan + publication as gs_launch_project
-void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s);
+void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s, bool publish);
 
 struct GsBinArgs {
     GsProf* prof;
@@ -233,7 +251,8 @@ struct GsBinArgs {
     // "predicted sizing").  M bounds the in-camera offsets (N rows when unknown); K is the pair capacity the launch geometry and
     // the buffers were sized for -- every kernel works on min(counters->K, K) pairs, read on the device.
     int64_t N; int M; uint32_t K; const GsCounters* counters; int H, W, tiles_x; float depth_scale; int depth_bits; int key_bits;
-    const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const int32_t* depth_codes; const uint32_t* tile_block_offsets;
+    const float4 *PA, *PB; const ushort4* box; const int32_t* ntiles; const int32_t* depth_codes; const uint32_t* tile_block_sums;
+    GsCounters* counters_rw; GsCounters* host_mirror; int32_t ticket;   // host_mirror != NULL: the last k_keygen block publishes the frame counters
     const int32_t *block_offsets, *block_counts;   // k_project's blocks (first in-camera offset, count); NULL: 256 consecutive records per block
     uint32_t* offsets;                          // (M) exclusive scan of ntiles, written by keygen
     void *keys_a, *keys_b; int32_t *vals_a, *vals_b;       // ping-pong (K); keys are u32, or u64 when key64
@@ -274,9 +293,9 @@ struct GsBackwardArgs {
     int split_heavy;                // 0: no tile is treated as heavy (GS_BWD_SPLIT_HEAVY=0)
     int strict;                     // gs_config.bwd_reference_order: loop 1's UTIL:331-348 in the reference's own operation order
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
-    uint8_t* visited;               // (K*G) 1 where the row of `partial` was written this backward
-    size_t visited_bytes;           // flags (K*G rounded up to 16), one all-zero 48-byte row, 16 bytes of padding, then `touched`: all cleared per backward
-    uint8_t* touched;               // (M) 1 where some pixel took a contribution from the point
+    uint8_t* visited;               // (K*G) == gen where the row of `partial` was written by this backward
+    uint8_t gen;                    // this backward's tag (1..255): flags are never cleared per backward, a stale one just does not match
+    uint8_t* touched;               // (M) == gen where some pixel took a contribution from the point
     const float4* zero_row;         // that row
     float4* sums;                   // (M,3) per-point sums of the visited rows (count as int32 bits in [10])
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;

@@ -32,13 +32,14 @@
 //     four ballots, and a quadrant body runs only for the (splat, quadrant) pairs that survive.
 // Pairs that are never visited (beyond every pixel's last index -- about three quarters of a
 // saturated tile's list -- or culled in all four quadrants) cost nothing: their rows are not
-// written and their `visited` byte stays 0 (the array is cleared by the k_tile_order launch of each backward).
+// written and their `visited` byte does not carry this backward's tag (the flags are tagged, never cleared per backward).
 // Tiles in order of decreasing backward work (entries to walk), so that the heaviest tiles are
 // dispatched first and the launch does not end on a few long-running waves.  Counting sort in one
 // workgroup: 2048 bins of width ORDER_BIN_WIDTH (more work shares the first bin).  Pure scheduling: results do
 // not depend on it.  Work = the (splat, quadrant) evaluations the forward counted for the tile.
 #define ORDER_BINS 2048
 #define ORDER_BIN_WIDTH 4
+#define ORDER_PER 8
 // HEAVY tiles: the first n_heavy entries of the order -- tiles whose work is at least HEAVY_FACTOR times the mean and at
 // least HEAVY_MIN_WORK evaluations (at most T / 8 of them, HEAVY_CAP in all).  k_blend_bwd_tile gives each of them a whole
 // workgroup (four cooperating waves, one per quadrant) instead of one wave: on a clustered scene a few tiles carry lists
@@ -49,27 +50,27 @@
 #define HEAVY_CAP 1024
 __host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? T / 8 : HEAVY_CAP; }
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,
-                                                     uint4* __restrict__ clear, size_t clear_vec, int32_t* __restrict__ n_heavy_out, int split_heavy)
+                                                     int32_t* __restrict__ n_heavy_out, int split_heavy)
 {
     __shared__ uint32_t bins[ORDER_BINS];
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long wtot[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (blockIdx.x > 0) {
-        // the other workgroups of the launch clear the `visited` flags (and the all-zero row behind them) for the blend
-        // that follows: one launch instead of a memset plus this kernel
-        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + t; i < clear_vec; i += (size_t)(gridDim.x - 1) * 1024)
-            clear[i] = make_uint4(0u, 0u, 0u, 0u);
-        return;
-    }
     for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
     __syncthreads();
     unsigned long long total = 0ull;
-    for (int i = t; i < T; i += 1024) {
-        const int work = tile_work[i];
-        total += (unsigned long long)(work > 0 ? work : 0);
-        int w = work / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
-        atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);               // bin 0 = heaviest
+    // ORDER_PER loads in flight per thread (the kernel is one workgroup deep in load latency, not in work)
+    for (int base = 0; base < T; base += 1024 * ORDER_PER) {
+        int work[ORDER_PER];
+#pragma unroll
+        for (int k = 0; k < ORDER_PER; ++k) { const int i = base + k * 1024 + t; work[k] = i < T ? tile_work[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < ORDER_PER; ++k) {
+            if (base + k * 1024 + t >= T) continue;
+            total += (unsigned long long)(work[k] > 0 ? work[k] : 0);
+            int w = work[k] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+            atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);           // bin 0 = heaviest
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
@@ -103,11 +104,19 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
         *n_heavy_out = n < cap ? n : cap;
     }
     __syncthreads();
-    for (int i = t; i < T; i += 1024) {
-        int w = tile_work[i] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
-        const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
-        order[pos] = i;
-        if (hint) hint[pos] = i;
+    for (int base = 0; base < T; base += 1024 * ORDER_PER) {
+        int work[ORDER_PER];
+#pragma unroll
+        for (int k = 0; k < ORDER_PER; ++k) { const int i = base + k * 1024 + t; work[k] = i < T ? tile_work[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < ORDER_PER; ++k) {
+            const int i = base + k * 1024 + t;
+            if (i >= T) continue;
+            int w = work[k] / ORDER_BIN_WIDTH; w = w < 0 ? 0 : (w > ORDER_BINS - 1 ? ORDER_BINS - 1 : w);
+            const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
+            order[pos] = i;
+            if (hint) hint[pos] = i;
+        }
     }
 }
 
@@ -142,7 +151,7 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
                                                  const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
                                                  const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
                                                  float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
-                                                 float* __restrict__ mag_image)
+                                                 const uint8_t gen, float* __restrict__ mag_image)
 {
 #ifdef GS_STATS
     const unsigned long long gs_t0 = wall_clock64();
@@ -372,7 +381,7 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
                         const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
                         float* row = partial + (size_t)sj * PW;
                         if ((lane & 3) == 0 && lane < 48) row[lane >> 2] = t;              // 12 floats (pad = 0), one store
-                        if (lane == 63) { visited[sj] = 1; touched[__builtin_amdgcn_readlane(p, j)] = 1; }   // row written; point has a contribution
+                        if (lane == 63) { visited[sj] = gen; touched[__builtin_amdgcn_readlane(p, j)] = gen; }   // row written; point has a contribution (this backward's tag)
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -401,7 +410,7 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
                     const uint32_t sj = (uint32_t)coop.slot[tj];
                     float* row = partial + (size_t)sj * PW + 3 * part;
                     row[0] = r0; row[1] = part == 3 ? __int_as_float(cnt) : r1; row[2] = r2;      // (column 11 is padding: 0)
-                    if (part == 0) { visited[sj] = 1; touched[coop.point[tj]] = 1; }
+                    if (part == 0) { visited[sj] = gen; touched[coop.point[tj]] = gen; }
                 }
                 __syncthreads();                                                            // the slabs are free for the next batch
             }
@@ -435,8 +444,11 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
 // takes four (tile, quadrant group) work items of the ordinary kind -- NQ = 4: four tiles, one wave each; NQ = 2: two tiles,
 // two waves each; NQ = 1: one tile.  The grid is sized for the largest possible number of heavy tiles (the host does not know
 // n_heavy); surplus workgroups leave at once.
+#ifndef GS_BWD_MIN_WAVES
+#define GS_BWD_MIN_WAVES 4        // waves per SIMD the register allocator must leave room for (6 spills 17 registers: measured slower)
+#endif
 template <int NQ, bool STRICT>
-__global__ __launch_bounds__(256, 4) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order, const int32_t* __restrict__ n_heavy_ptr, int T,
+__global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const int32_t* __restrict__ tile_order, const int32_t* __restrict__ n_heavy_ptr, int T,
                                                         const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
                                                         const int32_t* __restrict__ sorted_vals,
                                                         const float4* __restrict__ PA, const float4* __restrict__ PB,
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void k_blend_bwd_tile(const int32_t* __rest
                                                         const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
                                                         const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
                                                         float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
-                                                        float* __restrict__ mag_image)
+                                                        const uint8_t gen, float* __restrict__ mag_image)
 {
     __shared__ float4 sRecAll[4][64][3];             // per wave: the batch's splat records (COOP: then the per-quadrant sums)
     __shared__ __attribute__((aligned(16))) float sRedAll[4][11 * RED_STRIDE];
@@ -459,14 +471,14 @@ __global__ __launch_bounds__(256, 4) void k_blend_bwd_tile(const int32_t* __rest
     coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
     if ((int)blockIdx.x < n_heavy) {
         gs_bwd_tile_body<1, STRICT, true>(tile_order[blockIdx.x], wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
-                                          PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, mag_image);
+                                          PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
         return;
     }
     const int item = ((int)blockIdx.x - n_heavy) * 4 + wave;          // work item among the ordinary (tile, quadrant group) pairs
     const int ti = n_heavy + item / G;
     if (ti >= T) return;
     gs_bwd_tile_body<NQ, STRICT, false>(tile_order[ti], item % G, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
-                                        PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, mag_image);
+                                        PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
 }
 
 // ---------------------------------------------------------------------------------
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(256, 4) void k_blend_bwd_tile(const int32_t* __rest
 #define SUM_ROWS_SMALL 32
 __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
                                                   const float* __restrict__ partial, const uint8_t* __restrict__ visited, const uint8_t* __restrict__ touched,
-                                                  const float4* __restrict__ zero_row, float4* __restrict__ sums)
+                                                  const uint8_t gen, const float4* __restrict__ zero_row, float4* __restrict__ sums)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = t >> 2, q = t & 3;
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
     const bool valid = m < M;
     // a point no pixel took a contribution from (nine in ten at the headline config) has no visited row: its byte of
     // `touched` says so and none of its flags or rows is looked at
-    const bool live = valid && touched[m] != 0;
+    const bool live = valid && touched[m] == gen;
     const uint32_t off = live ? offsets[m] * (uint32_t)G : 0u;       // G rows per (point, tile) pair
     const int cnt = live ? ntiles[m] * G : 0;
     float v[11];
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
 #pragma unroll
         for (int k = 0; k < SUM_ROWS_SMALL / 4; ++k) {
             const int i = q + 4 * k;
-            const bool on = i < cnt && vis[i] != 0;
+            const bool on = i < cnt && vis[i] == gen;
             r[k] = on ? rows + 3 * i : zero_row;
         }
 #pragma unroll
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* 
 #pragma unroll
         for (int k = 0; k < 11; ++k) w[k] = 0.0f;
         for (int i = lane; i < bcnt; i += 64) {
-            if (vis[i]) {
+            if (vis[i] == gen) {
                 const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
                 w[0] += a.x; w[1] += a.y; w[2] += a.z; w[3] += a.w; w[4] += b.x; w[5] += b.y; w[6] += b.z; w[7] += b.w;
                 w[8] += c.x; w[9] += c.y; wpix += __float_as_int(c.z);
@@ -829,17 +841,14 @@ __global__ __launch_bounds__(256) void k_bwd_points(
 void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
-        // workgroup 0 orders the tiles, the rest clear the flags + the shared all-zero row behind them (16-byte units)
-        const size_t clear_vec = (a.visited_bytes + 15) / 16;
-        const unsigned clear_groups = (unsigned)((clear_vec + 4095) / 4096 < 1024 ? (clear_vec + 4095) / 4096 : 1024);
-        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1 + clear_groups, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint,
-                                                                                         reinterpret_cast<uint4*>(a.visited), clear_vec, a.n_heavy, a.split_heavy));
+        // (the `visited` / `touched` flags are not cleared per backward: a flag counts only if it holds THIS backward's tag, a.gen)
+        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint, a.n_heavy, a.split_heavy));
         // workgroups: at most gs_heavy_cap(T) heavy tiles + the ordinary work items four to a workgroup
         const unsigned groups = (unsigned)gs_heavy_cap(a.T) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
 #define GS_BWD_LAUNCH(NQ_, STRICT_)                                                                                                    \
         GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<groups, 256, 0, s>>>(a.tile_order, a.n_heavy, a.T, a.tile_start,  \
                  a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x,   \
-                 a.partial, a.visited, a.touched, a.mag_image))
+                 a.partial, a.visited, a.touched, a.gen, a.mag_image))
         if (a.G == 1) { if (a.strict) GS_BWD_LAUNCH(4, true); else GS_BWD_LAUNCH(4, false); }
         else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true); else GS_BWD_LAUNCH(2, false); }
         else { if (a.strict) GS_BWD_LAUNCH(1, true); else GS_BWD_LAUNCH(1, false); }
@@ -849,7 +858,7 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
     if (a.M > 0 && a.T > 0 && a.K > 0)
         GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited, a.touched,
-                                                                                  a.zero_row, a.sums));
+                                                                                  a.gen, a.zero_row, a.sums));
     else if (a.M > 0)
         (void)hipMemsetAsync(a.sums, 0, sizeof(float) * PW * (size_t)a.M, s);          // no pairs at all: every sum is zero
 }

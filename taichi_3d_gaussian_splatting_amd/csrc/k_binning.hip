@@ -26,14 +26,16 @@
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ depth_codes, const ushort4* __restrict__ boxes,
                                                 const int32_t* __restrict__ ntiles,
-                                                const uint32_t* __restrict__ tile_block_offsets,
+                                                const uint32_t* __restrict__ tile_block_sums,
                                                 const int32_t* __restrict__ block_offsets, const int32_t* __restrict__ block_counts,
                                                 int M, int tiles_x,
                                                 float depth_scale, int depth_bits, uint32_t K_cap,
                                                 uint32_t* __restrict__ offsets, KeyT* __restrict__ keys,
-                                                int32_t* __restrict__ vals)
+                                                int32_t* __restrict__ vals,
+                                                GsCounters* __restrict__ counters, volatile GsCounters* host_mirror, int32_t ticket)
 {
     __shared__ uint32_t ws[4];
+    __shared__ uint32_t wpre[4];
     __shared__ uint32_t sExcl[4][64];
     __shared__ ushort4 sBox[4][64];
     __shared__ KeyT sCode[4][64];
@@ -52,10 +54,21 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
     sExcl[wave][lane] = incl - n;
     sBox[wave][lane] = valid ? boxes[idx] : make_ushort4(0, 1, 0, 1);
     sCode[wave][lane] = valid ? (KeyT)(uint32_t)depth_codes[idx] : (KeyT)0;     // i32(depth * scale), RAST:159-160, from k_project
+    // first pair of this block = the tile counts of all blocks before it (RAST:913-922 across blocks): a few thousand L2-resident
+    // counters summed by the block itself, instead of a scan launch in between
+    uint32_t pre = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) pre += tile_block_sums[j];
+    pre = (uint32_t)gs_wave_sum_i((int)pre);
+    if (lane == 0) wpre[wave] = pre;
     __syncthreads();
+    const uint32_t block_base = wpre[0] + wpre[1] + wpre[2] + wpre[3];
+    // the last block knows K = its base + its own count: it hands the frame counters to the host when the launch was queued
+    // before the host had them (predicted sizing; k_project.hip: gs_publish_counters)
+    if (host_mirror && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        gs_publish_counters(counters, block_base + ws[0] + ws[1] + ws[2] + ws[3], host_mirror, ticket);
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += ws[w];
-    const uint32_t wave_base = tile_block_offsets[blockIdx.x] + woff;             // slot of the wave's first pair
+    const uint32_t wave_base = block_base + woff;                                 // slot of the wave's first pair
     if (valid) offsets[idx] = wave_base + incl - n;                               // RAST:913-922 (also the backward's row slots)
     const uint32_t wave_total = ws[wave];
     const int wave_first_point = first + (int)(threadIdx.x & ~63u);
@@ -292,7 +305,8 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
     if (a.N == 0 || a.M == 0) return;
     const unsigned kg_blocks = a.block_offsets ? (unsigned)((a.N + 255) / 256) : (unsigned)((a.M + 255) / 256);
     GS_TIMED(a.prof, KID_KEYGEN, s, k_keygen<KeyT><<<kg_blocks, 256, 0, s>>>(
-        a.depth_codes, a.box, a.ntiles, a.tile_block_offsets, a.block_offsets, a.block_counts, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a));
+        a.depth_codes, a.box, a.ntiles, a.tile_block_sums, a.block_offsets, a.block_counts, a.M, a.tiles_x, a.depth_scale, a.depth_bits, a.K, a.offsets, keys_a, a.vals_a,
+        a.counters_rw, a.host_mirror, a.ticket));
     if (a.K == 0) return;
     int nb, tpb;
     sort_geometry(a.K, &nb, &tpb);

@@ -14,6 +14,9 @@
 // Bound: FP32 VALU (exp polynomial + blend), not HBM: see DESIGN.md.
 #include "gs_common.h"
 #include "gs_cull.h"
+#ifndef GS_FWD_INT_MIN
+#define GS_FWD_INT_MIN 1
+#endif
 
 // find_tile_start_and_end (RAST:175-193) without a launch of its own: the first index of the sorted, compact keys
 // (tile << depth_bits | depth code) whose tile is >= `tile`, by a 64-ary search -- every step the wave's 64 lanes probe
@@ -138,7 +141,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
                 GS_STAT(2, 1);                                                                                                   \
                 float alpha = (ALPHA);                                                                                           \
                 unsigned long long use_m = gs_ballot(!(alpha < GS_ALPHA_EPS)) & (LIVE);   /* RAST:451 */                          \
-                alpha = alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX;                      /* RAST:453 */                          \
+                /* min(alpha, 0.99), RAST:453, as the UNSIGNED minimum of the bit patterns: one instruction (the float form costs a  */ \
+                /* canonicalising v_max first).  Same value for every alpha >= 0; a NaN of either sign gives 0.99 like the compare- */ \
+                /* and-select of the oracle; a negative alpha (never blended: it fails the 1/255 test) may come out as 0.99         */ \
+                alpha = GS_FWD_INT_MIN ? __uint_as_float(min(__float_as_uint(alpha), __float_as_uint(GS_ALPHA_MAX)))                \
+                                       : (alpha < GS_ALPHA_MAX ? alpha : GS_ALPHA_MAX);                                             \
                 const float next_T = T_i * (1.0f - alpha);                                /* RAST:457 */                          \
                 const unsigned long long sat_m = gs_ballot(next_T < GS_T_STOP) & use_m;   /* RAST:458-460 */                      \
                 alive &= ~sat_m;                                                                                                 \

@@ -1,7 +1,8 @@
 // k_project.hip -- per-point stages of the forward:
 //   k_filter         filter_point_in_camera, RAST:31-78, with the host prologue RAST:841-846 (inverse_SE3_qt_torch,
 //                    UTIL:426-432) folded in: every block derives the pose records itself
-//   k_scan_tiles_publish   exclusive scan of the per-block tile counts (replaces the torch cumsum glue) + hand-over of M, K
+//   k_scan_tiles_publish   hand-over of M, K and the depth-code range to the host when it has to wait for them (exact sizing);
+//                    with predicted sizing the last block of k_keygen does it and this launch does not exist
 //   k_project        point_id[mask] (RAST:861-870, ascending ids) + generate_point_attributes_in_camera_plane RAST:239-315
 //                    + generate_num_overlap_tiles RAST:106-128 in one kernel
 // All HBM-bound streaming kernels; layouts in DESIGN.md.
@@ -76,11 +77,14 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
                                                 const float* __restrict__ q_pc, const float* __restrict__ t_pc, int n_objects,
                                                 GsPose* __restrict__ pose, GsCounters* __restrict__ counters,
                                                 int64_t N, int W, int H, float near_plane, float far_plane,
-                                                int8_t* __restrict__ mask, int32_t* __restrict__ block_counts)
+                                                int8_t* __restrict__ mask, int32_t* __restrict__ block_counts,
+                                                int32_t* __restrict__ tile_arrays, int tile_ints)
 {
     __shared__ int wave_cnt[4];
     __shared__ GsPose sp[FILTER_POSE_CACHE];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // the frame's first kernel also clears tile_start | tile_end (RAST:954-957 zero-init) | tile_work for the binning and the blend
+    for (int64_t k = i; k < tile_ints; k += (int64_t)gridDim.x * 256) tile_arrays[k] = 0;
     // every block derives the (few) pose records itself -- same arithmetic as the stored ones -- so that no separate
     // pose launch has to finish first; block 0 stores them for the later kernels
     const bool cached = n_objects <= FILTER_POSE_CACHE;
@@ -322,11 +326,12 @@ __global__ __launch_bounds__(256) void k_boxes_from_records(const float4* __rest
                                                             const float4* __restrict__ PD, int M, int W, int H, float depth_scale,
                                                             ushort4* __restrict__ boxes, int32_t* __restrict__ ntiles,
                                                             uint32_t* __restrict__ tile_block_sums, GsCounters* counters,
-                                                            int32_t* __restrict__ depth_codes)
+                                                            int32_t* __restrict__ depth_codes, int32_t* __restrict__ tile_arrays, int tile_ints)
 {
     __shared__ int wave_sum[4];
     __shared__ int wave_max[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    for (int k = idx; k < tile_ints; k += (int)gridDim.x * 256) tile_arrays[k] = 0;       // as k_filter does
     int count = 0, depth_code = 0;
     if (idx < M) {
         const float4 A = GS_REC(PA, idx);
@@ -351,54 +356,36 @@ __global__ __launch_bounds__(256) void k_boxes_from_records(const float4* __rest
 }
 
 // ---------------------------------------------------------------------------------
-// Last kernel before the host has to know M, K and the depth-code range: exclusive scan of the per-block tile
-// counts (as k_scan_blocks), clear of the tile_start | tile_end | tile_work arrays (RAST:954-957 zero-init), and
-// publication of the frame counters straight into pinned host memory.  The host spins on `ticket` instead of
-// waiting for a copy + stream synchronisation (tens of microseconds of GPU idle per frame).
-__global__ __launch_bounds__(1024) void k_scan_tiles_publish(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
-                                                             GsCounters* __restrict__ counters, int32_t* __restrict__ tile_arrays, int tile_ints,
+// Hand-over of the frame counters to the host: M, K (= the sum of the per-block tile counts), the depth-code range and the
+// bad-object-id count go straight into pinned host memory, followed by the ticket the host waits for (spinning on it costs
+// a few microseconds where a copy + stream synchronisation left the GPU idle for tens).  Called by ONE thread that already
+// holds K.  Two places do it: k_scan_tiles_publish when the host needs the counters before it can queue the binning (exact
+// sizing), and the last block of k_keygen when the binning was queued on predicted sizes (gs_api.hip: run_forward_tail) --
+// then the frame has one launch fewer.
+__global__ __launch_bounds__(1024) void k_scan_tiles_publish(const uint32_t* __restrict__ in, int n, GsCounters* __restrict__ counters,
                                                              volatile GsCounters* host_mirror, int32_t ticket)
 {
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < tile_ints; i += 1024) tile_arrays[i] = 0;
-    if (threadIdx.x == 0) carry_s = 0;
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) v += in[i];
+    v = (uint32_t)gs_wave_sum_i((int)v);
+    if (lane == 0) wave_tot[wave] = v;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < n ? in[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
-        const uint32_t carry = carry_s;
-        if (i < n) out[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        const uint32_t K = carry_s;
-        counters->K = K;
-        host_mirror->M = counters->M;
-        host_mirror->K = K;
-        host_mirror->max_depth_code = counters->max_depth_code;
-        host_mirror->bad_object_ids = counters->bad_object_ids;
-        __threadfence_system();
-        host_mirror->reserved = ticket;              // the host waits for this value
-        __threadfence_system();
-        // the accumulating counters start the next frame at zero (zero at gs_create for the first one): no clearing
-        // launch, and no block of the next k_filter / k_project can run ahead of a clear
-        counters->max_depth_code = 0;
-        counters->bad_object_ids = 0;
+        uint32_t K = 0;
+        for (int w = 0; w < 16; ++w) K += wave_tot[w];
+        gs_publish_counters(counters, K, host_mirror, ticket);
     }
 }
 
-void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
+void gs_launch_publish(const GsProjectArgs& a, int n_blocks, hipStream_t s)
+{
+    if (n_blocks <= 0) return;
+    GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, n_blocks, a.counters, a.host_mirror, a.ticket));
+}
+
+void gs_launch_project(const GsProjectArgs& a, hipStream_t s, bool publish)
 {
     const int nb = (int)((a.N + 255) / 256);
     if (nb == 0) {
@@ -407,16 +394,15 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s)
     }
     GS_TIMED(a.prof, KID_FILTER, s, k_filter<<<nb, 256, 0, s>>>(a.point_cloud, a.invalid, a.object_id, a.Kmat, a.q_pc, a.t_pc, a.n_objects,
                                                             a.pose, a.counters, a.N, a.W, a.H, a.near_plane, a.far_plane, a.mask,
-                                                            a.block_counts));
+                                                            a.block_counts, a.tile_arrays, a.tile_ints));
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.mask, a.block_counts, a.N,
                                                               a.ids, a.cam_index, a.block_offsets, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
                                                               a.tile_block_sums, a.counters, a.depth_codes));
-    GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
-                                                                              a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
+    if (publish) gs_launch_publish(a, nb, s);
 }
 
-void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s)
+void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s, bool publish)
 {
     const int nb = (M + 255) / 256;
     if (nb == 0) {
@@ -424,7 +410,6 @@ void gs_launch_boxes_from_records(const GsProjectArgs& a, int M, hipStream_t s)
         return;
     }
     GS_TIMED(a.prof, KID_PROJECT, s, k_boxes_from_records<<<nb, 256, 0, s>>>(a.PA, a.PB, a.PD, M, a.W, a.H, a.depth_scale, a.box, a.ntiles,
-                                                                          a.tile_block_sums, a.counters, a.depth_codes));
-    GS_TIMED(a.prof, KID_PUBLISH, s, k_scan_tiles_publish<<<1, 1024, 0, s>>>(a.tile_block_sums, a.tile_block_offsets, nb, a.counters,
-                                                                              a.tile_arrays, a.tile_ints, a.host_mirror, a.ticket));
+                                                                          a.tile_block_sums, a.counters, a.depth_codes, a.tile_arrays, a.tile_ints));
+    if (publish) gs_launch_publish(a, nb, s);
 }

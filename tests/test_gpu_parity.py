@@ -670,3 +670,29 @@ def test_heavy_tiles_shared_by_four_waves_clustered_scene(P):
         lens = f.tile_points_end - f.tile_points_start
         assert lens.max() > 8 * lens.mean(), (lens.max(), lens.mean())
         assert module.last_frame.heavy_tiles() > 0, waves
+
+
+def test_flag_tags_wrap_round_after_255_backwards(P):
+    """The backward's `visited` / `touched` flags are tagged with a per-backward value 1..255 instead of being cleared (gs_api.hip:
+    prepare_backward_blend); after 255 backwards the buffer is zeroed and the tags start again.  Same bits before, at and
+    after the wrap, with a second scene of another size using the same buffer in between."""
+    a, b = synth(1500, 96, 64, 0.1, seed=51), synth(2500, 128, 96, 0.08, seed=52)
+    q, t = view_pose()
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig())
+
+    def grads(scene):
+        inp = P.make_input(scene, q, t)
+        img = module(inp)[0]
+        (img * img).sum().backward()
+        return inp.point_cloud.grad.cpu().numpy().copy(), inp.point_cloud_features.grad.cpu().numpy().copy()
+
+    ref_a, ref_b = grads(a), grads(b)
+    f, _ = P.run_oracle(a, q, t)
+    for it in range(3, 520):
+        if it % 7 == 0:
+            got, ref = grads(b), ref_b
+        else:
+            got, ref = grads(a), ref_a
+        if it in (253, 254, 255, 256, 257, 258, 509, 510, 511, 512) or it % 50 == 0:
+            assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), it
+            assert np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)), it
