@@ -100,8 +100,8 @@ typedef struct gs_forward_out {
     int32_t* pixel_valid_point_count;                /* device (H,W) i32 */
 } gs_forward_out;
 
-/* Data-dependent sizes of a frame (the reference learns them through two
- * device->host syncs, RAST:870 and RAST:916-931; here it is one). */
+/* Data-dependent sizes of a frame (the reference learns them through two device->host syncs in the middle of its forward,
+ * RAST:870 and RAST:916-931; here the host reads them once, after it has queued the whole forward -- see `sizing`). */
 typedef struct gs_frame_info {
     int64_t n_points;               /* N */
     int64_t n_points_in_camera;     /* M */
@@ -196,7 +196,13 @@ int gs_destroy(gs_ctx* ctx);
  * benchmark/inference_benchmark.py:110-156) and *frame_out still receives a handle
  * valid for gs_frame_get_info/gs_frame_export until the next call on this ctx.
  * When K == 0 the outputs are zero-filled (the reference leaves torch.empty
- * garbage, RAST:967-980). */
+ * garbage, RAST:967-980).
+ * Sizing: the per-pixel half (binning, sort, blend) needs M, K and the depth-code range only to size buffers and grids.  From
+ * the second frame of a ctx at an image size on, it is queued on PREDICTED sizes (the last frame's + 25 %) before the host has
+ * read the frame's counters; the kernels take the real pair count on the device and never leave the predicted capacity; the
+ * host reads the counters after its last launch and, if the prediction did not hold, queues the per-pixel half again with
+ * exact sizes before this call returns (gs_frame_info.sizing says which happened; GS_PREDICT_SIZES=0 disables prediction).
+ * Either way the outputs the caller sees are the exact ones, in stream order. */
 int gs_forward(gs_ctx* ctx, const gs_scene* scene, const gs_camera* camera, const gs_config* config,
                const gs_forward_out* out, int32_t keep_for_backward, gs_frame** frame_out, gs_stream stream);
 

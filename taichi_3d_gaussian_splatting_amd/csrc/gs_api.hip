@@ -122,7 +122,7 @@ struct gs_ctx {
     // scratch shared by all frames (stream ordered)
     DevBuf block_counts, block_offsets, tile_block_sums, hist, scan_tmp, counters, partial, visited, zero_row, sums, loss_ws;
     uint8_t visit_gen = 0;                 // tag of the last backward's flags in `visited` (0: the buffer is all zero)
-    GsCounters* host_counters = nullptr;   // pinned, device-visible, GS_COUNTER_SLOTS of them; written by k_scan_tiles_publish
+    GsCounters* host_counters = nullptr;   // pinned, device-visible, GS_COUNTER_SLOTS of them; written by gs_publish_counters (k_keygen's last block or k_scan_tiles_publish)
     GsCounters* host_counters_dev = nullptr;   // the device's address of it
     uint64_t slots_busy = 1ull;            // slot 0 serves the calls that wait at once; the others belong to frames begun and not yet read
     int32_t ticket = 0;                    // sequence number of the last forward
@@ -165,7 +165,7 @@ extern "C" int gs_create(int32_t device, gs_ctx** out)
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_counters_dev), c->host_counters, 0);
     if (e != hipSuccess) { (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
     e = c->counters.ensure(sizeof(GsCounters), &c->device_bytes);
-    if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(GsCounters));      // every later frame leaves them reset (k_scan_tiles_publish)
+    if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(GsCounters));      // every later frame leaves them reset (gs_publish_counters)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->switch_event, hipEventDisableTiming);
     if (e != hipSuccess) { c->counters.release(&c->device_bytes); (void)hipHostFree(c->host_counters); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: counters"); }
     *out = c;

@@ -1,13 +1,14 @@
 // k_backward.hip -- gaussian_point_rasterisation_backward, RAST:488-772, plus the torch
-// post-processing RAST:1102-1140, as three kernels and NO global atomics:
+// post-processing RAST:1102-1140, as three kernels (+ a tile ordering) and NO global atomics:
 //
+//   k_tile_order  tiles by decreasing work (scheduling only) and the number of HEAVY tiles at the head of that order.
 //   k_blend_bwd_tile  loop 1 (RAST:531-705).  One wave per tile walks the tile's list back to
-//                 front.  The 11 per-contribution quantities the reference sends to HBM with
-//                 ti.atomic_add (RAST:674-696) are summed over the tile's 256 pixels in
+//                 front (a heavy tile: a workgroup of four waves, a quadrant each).  The 11 per-contribution quantities the
+//                 reference sends to HBM with ti.atomic_add (RAST:674-696) are summed over the tile's 256 pixels in
 //                 registers + an LDS transpose and stored ONCE per (point, tile) pair as a 12-float
 //                 row of `partial`, at the pair's pre-sort slot (offsets[p] + position of the tile
 //                 in p's tile box), so all rows of a point are contiguous; a byte of `visited`
-//                 marks the rows that were written.  Factors that are constant per splat (opacity,
+//                 tags the rows this backward wrote.  Factors that are constant per splat (opacity,
 //                 0.5, (1 - opacity) * opacity) are left out of the rows and applied once per point.
 //   k_sum_rows    sums a point's visited rows in slot order (deterministic).
 //   k_bwd_points  loop 2 (RAST:708-772) over all N rows: chains the Jacobians (GP3D:132-159, 237-331, 351-373),

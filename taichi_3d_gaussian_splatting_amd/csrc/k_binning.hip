@@ -327,7 +327,7 @@ static void launch_binning_t(const GsBinArgs& a, hipStream_t s)
 
 void gs_launch_binning(const GsBinArgs& a, hipStream_t s)
 {
-    // tile_start | tile_end (RAST:954-957 zero-init) | tile_work were cleared by gs_launch_project
+    // tile_start | tile_end (RAST:954-957 zero-init) | tile_work were cleared by the frame's first kernel (k_filter / k_boxes_from_records)
     if (a.key64) launch_binning_t<uint64_t>(a, s);
     else launch_binning_t<uint32_t>(a, s);
 }

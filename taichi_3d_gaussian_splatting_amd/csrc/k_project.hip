@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_filter(const float* __restrict__ pc, co
     // pose launch has to finish first; block 0 stores them for the later kernels
     const bool cached = n_objects <= FILTER_POSE_CACHE;
     if (cached && threadIdx.x < n_objects) sp[threadIdx.x] = make_pose(q_pc, t_pc, threadIdx.x);
-    if (blockIdx.x == 0) {            // (the frame counters were reset by the previous frame's k_scan_tiles_publish)
+    if (blockIdx.x == 0) {            // (the frame counters were reset when the previous frame's were published)
         for (int o = threadIdx.x; o < n_objects; o += 256) pose[o] = make_pose(q_pc, t_pc, o);
     }
     __syncthreads();

@@ -4,7 +4,7 @@ Same names and argument meaning as the helpers the reference's callers use aroun
 rasteriser (taichi_3d_gaussian_splatting/utils.py:396-492, 596-632); quaternions are
 (x, y, z, w).  The rasteriser itself does not call these: the pose inversion the reference
 performs with inverse_SE3_qt_torch at GaussianPointCloudRasterisation.py:845 runs inside
-libgsrast.so (k_pose_prepare).  They are here so callers that build poses keep working.
+libgsrast.so (every k_filter block derives the pose records itself).  They are here so callers that build poses keep working.
 """
 from typing import Tuple
 

@@ -40,14 +40,15 @@ def _grad_of_image(img):
     return 2.0 * (img - 0.4)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo", own_device=False):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if own_device else 0), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Rast
     from taichi_3d_gaussian_splatting_amd import distributed as gsd
     from taichi_3d_gaussian_splatting_amd.synthetic import view_pose
-    gsd.init_from_env("gloo")
-    dev = torch.device("cuda", 0)
+    gsd.init_from_env(backend)
+    dev = torch.device("cuda", rank if own_device else 0)
     torch.cuda.set_device(dev)
     s = _scene()
     poses = [tuple(torch.tensor(x, device=dev) for x in view_pose(v, world)) for v in range(world)]
@@ -97,8 +98,19 @@ def _free_port():
 
 
 def test_two_ranks_on_one_gpu_gaussian_parallel_and_view_parallel(tmp_path):
+    _two_ranks(tmp_path, "gloo", False)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the same two schemes with one card per rank over RCCL (backend nccl)")
+def test_two_ranks_on_two_gpus_over_rccl(tmp_path):
+    """The code paths a one-GPU box cannot reach: dist.all_to_all_single with uneven splits, the asynchronous all-reduce on RCCL's
+    own stream beside the compute stream (OverlappedGradientReducer), all_gather of the count table -- same bit-exact bars."""
+    _two_ranks(tmp_path, "nccl", True)
+
+
+def _two_ranks(tmp_path, backend, own_device):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend, own_device), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Rast
     from taichi_3d_gaussian_splatting_amd.distributed import shard_bounds

@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/taichi_3d_gaussian_splatting_amd/csrc
+src=${SRC_DIR:-$root/taichi_3d_gaussian_splatting_amd/csrc}
 obj=$root/build_ab/obj_$name
 mkdir -p $obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
