@@ -39,6 +39,7 @@ buf = (C.c_ulonglong * (2 * nrec))()
 _native.lib().gs_debug_wave_times_read(buf, nrec)
 a = np.array(buf, dtype=np.uint64).reshape(nrec, 2).astype(np.int64)
 a = a[a[:, 1] > a[:, 0]]
+a = a[a[:, 1] > np.percentile(a[:, 0], 10)]        # (a wave that left at once wrote nothing: its slot still holds a stamp of the forward blend, which ended before this launch began)
 T = a.shape[0]
 print(f"{wl}: {n_heavy} heavy tiles (4 cooperating waves each), {G} wave(s) per ordinary tile")
 t0 = a[:, 0].min()
