@@ -223,8 +223,9 @@ int gs_backward(gs_ctx* ctx, gs_frame* frame, const gs_scene* scene, const gs_ca
 
 /* May be called any number of times between forward and release (backward(retain_graph=True) in PyTorch terms). */
 
-/* Diagnostic: how many tiles the last backward blend of this frame treated as HEAVY (a workgroup of four cooperating waves
- * instead of one wave; k_backward.hip).  Scheduling only -- results do not depend on it.  Synchronises the stream. */
+/* Diagnostic: n_out[0] = how many tiles the last backward blend of this frame treated as HEAVY (a workgroup of four cooperating
+ * waves instead of one wave; k_backward.hip), n_out[1] = how many work items they were handed out as (a heavy tile whose list the
+ * forward cut is walked in segments of 512 entries, one item each).  n_out: host int32[2].  Synchronises the stream. */
 int gs_frame_heavy_tiles(gs_ctx* ctx, const gs_frame* frame, int32_t* n_out, gs_stream stream);
 
 int gs_frame_release(gs_ctx* ctx, gs_frame* frame);

@@ -110,12 +110,13 @@ class _Frame:
             _native.check(L.gs_frame_export(self._context.handle, self.handle, eid, _ptr(out), C.c_void_p(stream)), f"gs_frame_export({name})")
         return out
 
-    def heavy_tiles(self) -> int:
-        """Diagnostic: tiles the last backward blend of this frame shared among four waves (gs_frame_heavy_tiles)."""
-        n = C.c_int32(0)
+    def heavy_tiles(self, items: bool = False) -> int:
+        """Diagnostic: tiles the last backward blend of this frame shared among four waves, or (items=True) the work items they were
+        handed out as -- one per 512-entry segment of a list the forward cut (gs_frame_heavy_tiles)."""
+        n = (C.c_int32 * 2)(0, 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(_native.lib().gs_frame_heavy_tiles(self._context.handle, self.handle, C.byref(n), C.c_void_p(stream)), "gs_frame_heavy_tiles")
-        return int(n.value)
+        _native.check(_native.lib().gs_frame_heavy_tiles(self._context.handle, self.handle, n, C.c_void_p(stream)), "gs_frame_heavy_tiles")
+        return int(n[1] if items else n[0])
 
     def release(self):
         """Hands the ticket back.  Transient frames (forward without gradient tracking) belong to the context and are

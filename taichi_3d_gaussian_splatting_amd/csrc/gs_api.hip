@@ -51,12 +51,12 @@ struct DevBuf {
 
 // What RAST:998-1019 saves for backward, in this library's layouts (DESIGN.md "HBM layout").
 struct FrameBufs {
-    DevBuf mask, ids, cam_index, rec, box, ntiles, depth_codes, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order;
+    DevBuf mask, ids, cam_index, rec, box, ntiles, depth_codes, offsets, keys_a, keys_b, vals_a, vals_b, tile_start, pose, tile_order, cuts, cut_mag;
     bool in_use = false;
     void release(int64_t* total)
     {
         DevBuf* all[] = { &mask, &ids, &cam_index, &rec, &box, &ntiles, &depth_codes, &offsets, &keys_a, &keys_b, &vals_a, &vals_b,
-                          &tile_start, &pose, &tile_order };
+                          &tile_start, &pose, &tile_order, &cuts, &cut_mag };
         for (DevBuf* b : all) b->release(total);
     }
 };
@@ -72,6 +72,7 @@ struct Frame {
     int key64 = 0;
     int32_t* vals_sorted = nullptr;
     bool live = false;
+    int cut_cap = 0;                    // list-cut records the forward of this frame could claim (0: it wrote none)
     int bwd_reference_order = 0;        // gs_config.bwd_reference_order of the forward that made the frame (gs_backward_projected has no config)
     uint32_t generation = 0;
     // gs_project_shard_begin: the hand-over of M (and the object-id check) has not been read yet; slot of the pinned counters
@@ -281,6 +282,7 @@ static hipError_t enter_stream(gs_ctx* c, hipStream_t s)
     return hipSuccess;
 }
 
+static int waves_per_tile(int n_tiles);
 static int bits_for(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b < 1 ? 1 : b; }
 
 #define ENSURE(buf, bytes)                                                                 \
@@ -403,8 +405,8 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     ENSURE(B.mask, Np); ENSURE(B.ids, 4 * Np); ENSURE(B.cam_index, 4 * Np);
     ENSURE(B.rec, 64 * Np);
     ENSURE(B.box, 8 * Np); ENSURE(B.ntiles, 4 * Np); ENSURE(B.depth_codes, 4 * Np); ENSURE(B.offsets, 4 * Np);
-    ENSURE(B.tile_start, 3 * 4 * (size_t)T);      // tile_start | tile_end | tile_work, cleared together
-    ENSURE(B.tile_order, 4 * ((size_t)T + 4));     // + the number of heavy tiles behind the order
+    ENSURE(B.tile_start, 4 * GS_TILE_INTS(T));    // tile_start | tile_end | tile_work | tile_cut | cut_alloc, cleared together
+    ENSURE(B.tile_order, 4 * GS_ORDER_INTS(T));   // + heavy-tile count, item count and item bases behind the order
     ENSURE(B.pose, sizeof(GsPose) * (size_t)cam->n_objects);
     ENSURE(c->block_counts, 4 * (nb + 1)); ENSURE(c->block_offsets, 4 * (nb + 1));
     ENSURE(c->tile_block_sums, 4 * (nb + 1));
@@ -422,7 +424,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
-    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
+    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = (int)GS_TILE_INTS(T);
     int slot = 0;
     if (wait == WAIT_FRAME && N > 0) {
         const uint64_t free_slots = ~c->slots_busy;
@@ -450,6 +452,19 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
                             int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s, bool publish)
 {
     FrameBufs& B = *f->bufs;
+    // list cuts for the backward's heavy tiles (k_blend_fwd): only a frame that will be back-propagated wants them.  Records are
+    // claimed per long list; a full buffer just means fewer tiles with cuts, never an error.
+    // Policy (measured): segments pay where the ordinary waves do not fill the chip anyway (T * G waves for 5120
+    // slots: cfg2_clustered 0.38 -> 0.22 ms) and cost where they do (cfg3_clustered 0.31 -> 0.34 ms: more, shorter work items in a
+    // launch that was already full).  GS_BWD_SEGMENTS=0 / 1 forces never / always.
+    static const int seg_env = []{ const char* e = getenv("GS_BWD_SEGMENTS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool want_cuts = seg_env >= 0 ? seg_env == 1 : (int64_t)T * waves_per_tile(T) < 6144;
+    int cut_cap = 0;
+    if (want_cuts && f->info.kept_for_backward && !cfg->rgb_only && K_bound > 0) {
+        cut_cap = (int)std::max<uint64_t>(4096, (uint64_t)K_bound / 2048);
+        ENSURE(B.cuts, (size_t)cut_cap * 256 * sizeof(float4)); ENSURE(B.cut_mag, (size_t)cut_cap * 256 * sizeof(float2));
+    }
+    f->cut_cap = cut_cap;
     const int tile_bits = bits_for((uint32_t)(T > 1 ? T - 1 : 1));
     const int key64 = depth_bits + tile_bits > 32 ? 1 : 0;      // compact 32-bit keys whenever they fit
     if (depth_bits + tile_bits > 63) { drop_frame(c, f); return fail(GS_ERR_INVALID_ARGUMENT, "sort key needs more than 63 bits"); }
@@ -485,6 +500,8 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     fa.image = out->rasterized_image; fa.depth = out->rasterized_depth; fa.acc_alpha = out->pixel_accumulated_alpha;
     fa.last = out->pixel_offset_of_last_effective_point; fa.count = out->pixel_valid_point_count;
     fa.tile_work = B.tile_start.as<int32_t>() + 2 * (size_t)T;
+    fa.cuts = cut_cap > 0 ? B.cuts.as<float4>() : nullptr; fa.tile_cut = B.tile_start.as<int32_t>() + 3 * (size_t)T;
+    fa.cut_alloc = B.tile_start.as<int32_t>() + 4 * (size_t)T; fa.cut_cap = cut_cap;
     static const bool use_hint = []{ const char* e = getenv("GS_FWD_ORDER_HINT"); return !(e && e[0] == '0'); }();
     fa.order_hint = (use_hint && c->order_hint_T == T && T > 0) ? c->order_hint.as<int32_t>() : nullptr;
     // tile ranges are all zero when K == 0, so the kernel writes the "no contributor" values itself
@@ -581,6 +598,7 @@ extern "C" int gs_forward(gs_ctx* c, const gs_scene* sc, const gs_camera* cam, c
     Frame* f = acquire_frame(c, &slot);
     f->bufs = acquire_bufs(c);
     f->info = gs_frame_info{};
+    f->info.kept_for_backward = keep ? 1 : 0;      // (known before the stages run: a kept frame gets list cuts for its backward)
     const int T = tiles_x * tiles_y;
     GsProjectArgs pa{};
     int M = 0, max_code = 0; uint32_t K = 0;
@@ -609,6 +627,7 @@ extern "C" int gs_project_shard(gs_ctx* c, const gs_scene* sc, const gs_camera* 
     Frame* f = acquire_frame(c, &slot);
     f->bufs = acquire_bufs(c);
     f->info = gs_frame_info{};
+    f->info.kept_for_backward = keep ? 1 : 0;      // (known before the stages run: a kept frame gets list cuts for its backward)
     const int T = tiles_x * tiles_y;
     GsProjectArgs pa{};
     int M = 0, max_code = 0; uint32_t K = 0;
@@ -658,6 +677,7 @@ extern "C" int gs_project_shard_begin(gs_ctx* c, const gs_scene* sc, const gs_ca
     Frame* f = acquire_frame(c, &slot);
     f->bufs = acquire_bufs(c);
     f->info = gs_frame_info{};
+    f->info.kept_for_backward = keep ? 1 : 0;      // (known before the stages run: a kept frame gets list cuts for its backward)
     const int T = tiles_x * tiles_y;
     GsProjectArgs pa{};
     int M = 0, max_code = 0; uint32_t K = 0;
@@ -684,12 +704,13 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     Frame* f = acquire_frame(c, &slot);
     f->bufs = acquire_bufs(c);
     f->info = gs_frame_info{};
+    f->info.kept_for_backward = keep ? 1 : 0;      // (known before the stages run: a kept frame gets list cuts for its backward)
     FrameBufs& B = *f->bufs;
     const int T = tiles_x * tiles_y, H = cam->camera_height, W = cam->camera_width;
     const size_t Mp = (size_t)(m > 0 ? m : 1);
     const size_t nb = (size_t)((m + 255) / 256);
     ENSURE(B.rec, 64 * Mp); ENSURE(B.box, 8 * Mp); ENSURE(B.ntiles, 4 * Mp); ENSURE(B.depth_codes, 4 * Mp); ENSURE(B.offsets, 4 * Mp);
-    ENSURE(B.tile_start, 3 * 4 * (size_t)T); ENSURE(B.tile_order, 4 * ((size_t)T + 4));
+    ENSURE(B.tile_start, 4 * GS_TILE_INTS(T)); ENSURE(B.tile_order, 4 * GS_ORDER_INTS(T));
     ENSURE(c->tile_block_sums, 4 * (nb + 1));
     if (m > 0) HIP_TRY_F(hipMemcpyAsync(B.rec.p, records, (size_t)m * 64, hipMemcpyDeviceToDevice, s));   // the frame keeps its own copy for backward
     GsProjectArgs pa{};
@@ -698,7 +719,7 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     pa.box = B.box.as<ushort4>(); pa.ntiles = B.ntiles.as<int32_t>(); pa.depth_codes = B.depth_codes.as<int32_t>();
     pa.tile_block_sums = c->tile_block_sums.as<uint32_t>();
     pa.counters = c->counters.as<GsCounters>();
-    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = 3 * T;
+    pa.tile_arrays = B.tile_start.as<int32_t>(); pa.tile_ints = (int)GS_TILE_INTS(T);
     pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_boxes_from_records(pa, (int)m, s, false);       // the counters are published from run_forward_tail
@@ -854,8 +875,14 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.visited = c->visited.as<uint8_t>();
     a.G = G;
     a.n_heavy = B.tile_order.as<int32_t>() + f->info.n_tiles;
-    static const bool split_heavy = []{ const char* e = getenv("GS_BWD_SPLIT_HEAVY"); return !(e && e[0] == '0'); }();
-    a.split_heavy = split_heavy ? 1 : 0;
+    a.cuts = f->cut_cap > 0 ? B.cuts.as<float4>() : nullptr; a.cut_mag = B.cut_mag.as<float2>();
+    a.tile_cut = B.tile_start.as<int32_t>() + 3 * (size_t)f->info.n_tiles;
+    // heavy-tile threshold in half-means of work: sharing a tile among four waves costs more work in total and shortens the launch
+    // only where long walks are what the launch waits for; twice the mean measured best on both clustered workloads and changes
+    // nothing on the uniform ones (max / mean = 2).  GS_BWD_HEAVY_X2 overrides; GS_BWD_SPLIT_HEAVY=0 = no heavy tiles.
+    static const int heavy_env = []{ const char* e = getenv("GS_BWD_SPLIT_HEAVY"); if (e && e[0] == '0') return 0;
+                                     const char* x = getenv("GS_BWD_HEAVY_X2"); return x ? atoi(x) : -1; }();
+    a.heavy_factor_x2 = heavy_env >= 0 ? heavy_env : 4;
     a.strict = strict ? 1 : 0;
     a.gen = c->visit_gen;
     a.touched = c->visited.as<uint8_t>() + flag_bytes;
@@ -1049,11 +1076,11 @@ extern "C" int gs_frame_heavy_tiles(gs_ctx* c, const gs_frame* h, int32_t* n_out
     std::lock_guard<std::mutex> lock(c->mu);
     Frame* f = resolve(c, h);
     if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_heavy_tiles: not a live frame of this context");
-    if (!(f->info.stages & GS_STAGE_RASTER) || f->info.n_tiles <= 0 || !f->bufs->tile_order.p) { *n_out = 0; return GS_OK; }
+    if (!(f->info.stages & GS_STAGE_RASTER) || f->info.n_tiles <= 0 || !f->bufs->tile_order.p) { n_out[0] = n_out[1] = 0; return GS_OK; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     HIP_TRY(enter_stream(c, s));
-    HIP_TRY(hipMemcpyAsync(n_out, f->bufs->tile_order.as<int32_t>() + f->info.n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_out, f->bufs->tile_order.as<int32_t>() + f->info.n_tiles, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return GS_OK;
 }

@@ -43,6 +43,16 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #define GS_ALPHA_MAX 0.99f           // RAST:453
 #define GS_T_STOP 0.0001f            // RAST:458
 #define GS_NFEAT 56
+// Cuts of long tile lists (k_blend_fwd writes them, the backward blend of a HEAVY tile starts its segments from them): every
+// GS_SEG entries of a list longer than GS_CUT_MIN_LEN the forward stores each pixel's transmittance and accumulated colour.
+#define GS_SEG 512
+#define GS_CUT_MIN_LEN 1024
+#define GS_HEAVY_CAP 1024            // most tiles a backward treats as heavy
+#define GS_ITEM_CAP 4096             // most (heavy tile, segment) work items of a backward
+// tile arrays of a frame, cleared by its first kernel: tile_start | tile_end | tile_work | tile_cut (first cut record + 1, 0 = none) | cut_alloc
+#define GS_TILE_INTS(T) (4 * (size_t)(T) + 4)
+// tile_order buffer: order (T) | n_heavy | n_items | pad pad | item_base (GS_HEAVY_CAP + 1)
+#define GS_ORDER_INTS(T) ((size_t)(T) + 4 + GS_HEAVY_CAP + 4)
 
 // Per-object pose record built once per frame (every k_filter block derives it, block 0 stores it).
 struct GsPose {
@@ -275,6 +285,7 @@ struct GsBlendFwdArgs {
     const float4 *PA, *PB, *PC;
     float* image; float* depth; float* acc_alpha; int32_t* last; int32_t* count;
     int32_t* tile_work;            // (T) zeroed together with the tile ranges; max over the tile's pixels of last - start
+    float4* cuts; int32_t* tile_cut; int32_t* cut_alloc; int cut_cap;    // list cuts for the backward (cut_cap == 0: none wanted)
     const int32_t* order_hint;     // (T) or NULL: a permutation of the tiles, heaviest first, from an earlier frame of this ctx (scheduling only)
 };
 void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s);
@@ -289,8 +300,9 @@ struct GsBackwardArgs {
     const int32_t* ids; const int32_t* cam_index;
     const float* grad_image; const float* acc_alpha; const int32_t* last;
     int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
-    int32_t* n_heavy;               // device: number of heavy tiles at the head of tile_order (k_tile_order -> k_blend_bwd_tile)
-    int split_heavy;                // 0: no tile is treated as heavy (GS_BWD_SPLIT_HEAVY=0)
+    int32_t* n_heavy;               // device: number of heavy tiles at the head of tile_order (k_tile_order -> k_blend_bwd_tile); n_items and item_base follow it
+    const float4* cuts; float2* cut_mag; const int32_t* tile_cut;    // list cuts of the forward (NULL: none), per-segment |d uv| partial sums
+    int heavy_factor_x2;            // a tile is heavy from this many half-means of work on; 0: no tile is (GS_BWD_SPLIT_HEAVY=0)
     int strict;                     // gs_config.bwd_reference_order: loop 1's UTIL:331-348 in the reference's own operation order
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order
     uint8_t* visited;               // (K*G) == gen where the row of `partial` was written by this backward

@@ -41,19 +41,26 @@
 #define ORDER_BINS 2048
 #define ORDER_BIN_WIDTH 4
 #define ORDER_PER 8
-// HEAVY tiles: the first n_heavy entries of the order -- tiles whose work is at least HEAVY_FACTOR times the mean and at
-// least HEAVY_MIN_WORK evaluations (at most T / 8 of them, HEAVY_CAP in all).  k_blend_bwd_tile gives each of them a whole
+// HEAVY tiles: the first n_heavy entries of the order -- tiles whose work is at least heavy_factor_x2 / 2 times the mean (the host's
+// choice: twice the mean) and at least HEAVY_MIN_WORK evaluations (at most T / 8 of them, HEAVY_CAP in all).  k_blend_bwd_tile gives each of them a whole
 // workgroup (four cooperating waves, one per quadrant) instead of one wave: on a clustered scene a few tiles carry lists
 // ten to twenty times the mean and their single waves ARE the launch (profiles/r03_*_wave_timeline*.txt); on the uniform
 // generator (max / mean = 2) there are none.  Scheduling only, like the order itself.
-#define HEAVY_FACTOR 3
 #define HEAVY_MIN_WORK 1024
-#define HEAVY_CAP 1024
+#define HEAVY_CAP GS_HEAVY_CAP
 __host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? T / 8 : HEAVY_CAP; }
+// A heavy tile whose list the forward CUT (k_blend_fwd: every GS_SEG entries each pixel's T and accumulated colour) is handed out
+// as one work item per segment: item_base[h] .. item_base[h + 1] are the items of heavy tile h (n_heavy_out[1] = their number,
+// n_heavy_out[4 ..] = item_base).  A heavy tile without cuts is one item.
+__host__ __device__ inline int gs_item_cap(int T) { const int c = 4 * T; return c < GS_ITEM_CAP ? c : GS_ITEM_CAP; }
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,
-                                                     int32_t* __restrict__ n_heavy_out, int split_heavy)
+                                                     int32_t* __restrict__ n_heavy_out, int heavy_factor_x2,
+                                                     const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                     const int32_t* __restrict__ tile_cut)
 {
     __shared__ uint32_t bins[ORDER_BINS];
+    __shared__ int32_t sHeavy[HEAVY_CAP];
+    __shared__ int32_t sNHeavy;
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long wtot[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -95,14 +102,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
         unsigned long long sum = 0ull;
         for (int w = 0; w < 16; ++w) sum += wtot[w];
         const unsigned long long mean = T > 0 ? sum / (unsigned long long)T : 0ull;
-        unsigned long long thr = HEAVY_FACTOR * mean;
+        unsigned long long thr = (unsigned long long)heavy_factor_x2 * mean / 2ull;
         if (thr < HEAVY_MIN_WORK) thr = HEAVY_MIN_WORK;
         unsigned long long bw = (thr + ORDER_BIN_WIDTH - 1) / ORDER_BIN_WIDTH;              // first bin (by work) that counts as heavy
         if (bw > ORDER_BINS - 1) bw = ORDER_BINS - 1;                                       // (everything beyond the last bin edge shares it)
         int n = 0;
-        if (split_heavy) n = (int)bins[ORDER_BINS - (int)bw];                               // start of the heaviest light bin = number of heavier tiles
+        if (heavy_factor_x2 > 0) n = (int)bins[ORDER_BINS - (int)bw];                               // start of the heaviest light bin = number of heavier tiles
         const int cap = gs_heavy_cap(T);
-        *n_heavy_out = n < cap ? n : cap;
+        sNHeavy = n < cap ? n : cap;
+        *n_heavy_out = sNHeavy;
     }
     __syncthreads();
     for (int base = 0; base < T; base += 1024 * ORDER_PER) {
@@ -117,8 +125,38 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
             const uint32_t pos = atomicAdd(&bins[ORDER_BINS - 1 - w], 1u);
             order[pos] = i;
             if (hint) hint[pos] = i;
+            if (pos < HEAVY_CAP) sHeavy[pos] = i;
         }
     }
+    __syncthreads();
+    // work items of the heavy tiles: one per segment of a cut list (exclusive scan over at most 1024 tiles, one per thread)
+    const int n_heavy = sNHeavy;
+    int nseg = 0;
+    if (t < n_heavy) {
+        const int tile = sHeavy[t];
+        const int L = tile_end[tile] - tile_start[tile];
+        nseg = (tile_cut && tile_cut[tile] > 0 && L > 0) ? (L - 1) / GS_SEG + 1 : 1;
+    }
+    // Segments are handed out heaviest tile first for as long as the grid's item capacity lasts (every later tile still needs one item):
+    // inclusive scan of the wanted counts; a tile keeps its segments while (items up to and including it) + (tiles after it) fits.
+    auto block_scan = [&](uint32_t x, uint32_t& excl, uint32_t& total_out) {
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wo = 0, tt = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) wo += wsum[w]; tt += wsum[w]; }
+        excl = wo + inc - x; total_out = tt;
+    };
+    uint32_t ibase = 0, total_items = 0;
+    block_scan((uint32_t)nseg, ibase, total_items);
+    const int cap = gs_item_cap(T);
+    if (t < n_heavy && (int)(ibase + (uint32_t)nseg) + (n_heavy - 1 - t) > cap) nseg = 1;
+    block_scan((uint32_t)nseg, ibase, total_items);
+    if (t < n_heavy) n_heavy_out[4 + t] = (int32_t)ibase;
+    if (t == 0) { n_heavy_out[4 + n_heavy] = (int32_t)total_items; n_heavy_out[1] = (int32_t)total_items; }
 }
 
 // W = sum over the splats behind of (colour . pixel gradient) * alpha * T: the reference's three accumulated colours
@@ -140,7 +178,11 @@ struct QuadState { float T, W, gr, gg, gb, tot0, tot1; int last; };
 // 48-byte record is dead, and twelve floats is what a row holds), and after the batch the workgroup adds the four slabs up and
 // stores ONE row per pair -- the same rows, flags and per-point sums as the single-wave form, a heavy tile's critical path
 // cut to a quarter of the quadrant evaluations.  (Summation order within a pair: quadrants 0..3, each summed as before.)
-struct BwdCoop { unsigned long long* done; int32_t* slot; int32_t* point; int32_t* tile_last; float (*slab)[64][12]; };
+struct BwdCoop { unsigned long long* done; int32_t* slot; int32_t* point; int32_t* tile_last; float (*slab)[64][12];
+                 // the SEGMENT of the tile's list this workgroup walks (seg of nseg; nseg == 1: the whole list), the forward's cut
+                 // records of the tile (256 float4 each; record k: T before entry start + (k + 1) GS_SEG and the colour blended in
+                 // segment k; record nseg - 1: the final T and the last segment's colour) and where a segment leaves its |d uv| sums
+                 int seg, nseg; const float4* cut_rec; float2* mag_part; };
 
 template <int NQ, bool STRICT, bool COOP>
 __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, const int G_rows, float4 (*sRec)[3], float* sRed, const BwdCoop coop,
@@ -160,6 +202,9 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
     const int lane = threadIdx.x & 63;
     const int tile_u = tile % tiles_x, tile_v = tile / tiles_x;
     const int start = tile_start[tile], end = tile_end[tile];
+    // COOP with a cut list: this workgroup owns entries [seg_lo, seg_hi) only
+    const int seg_lo = (COOP && coop.nseg > 1) ? start + coop.seg * GS_SEG : start;
+    const int seg_hi = (COOP && coop.nseg > 1 && coop.seg < coop.nseg - 1) ? start + (coop.seg + 1) * GS_SEG : end;
     const int lx = lane & 7, ly = lane >> 3;
     QuadState Q[NQ];
     int qlast[NQ];
@@ -176,6 +221,28 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
         Q[qi].W = 0.0f;
         Q[qi].gr = grad_image[3 * o]; Q[qi].gg = grad_image[3 * o + 1]; Q[qi].gb = grad_image[3 * o + 2];
         Q[qi].tot0 = Q[qi].tot1 = 0.0f;
+        if constexpr (COOP) {
+            // A segment that does not end the list starts from the forward's records: the pixel's transmittance at the cut, and
+            // W = (colour blended BEHIND the cut) . (pixel gradient), the later segments' colours added up from the back -- small
+            // terms first, as the reference's own back-to-front accumulation does (RAST:656).  A pixel whose last contributor
+            // lies before the cut takes nothing from beyond it: its final state stands.
+            if (coop.nseg > 1 && coop.seg < coop.nseg - 1 && Q[qi].last >= seg_hi) {
+                const float4* rec = coop.cut_rec + grp * 64 + lane;
+                float br = 0.0f, bg = 0.0f, bb = 0.0f, t_final = 1.0f;
+                for (int k = coop.nseg - 1; k > coop.seg; --k) {
+                    const float4 r = rec[(size_t)k * 256];
+                    if (k == coop.nseg - 1) t_final = r.x;
+                    br += r.y; bg += r.z; bb += r.w;
+                }
+                // The reference's backward does not know the forward's T: it starts from 1 - accumulated_alpha (RAST:559-560), which
+                // has lost up to 6e-8 / T of a dim pixel's final T, and every T and every accumulated colour of that pixel's walk
+                // carries that factor.  The records hold the forward's exact values; scaled by (1 - accumulated_alpha) / (final T)
+                // they are what the reference's division chain arrives at.
+                const float ratio = t_final > 0.0f ? Q[qi].T / t_final : 1.0f;
+                Q[qi].T = rec[(size_t)coop.seg * 256].x * ratio;
+                Q[qi].W = ((Q[qi].gr * br + Q[qi].gg * bg) + Q[qi].gb * bb) * ratio;
+            }
+        }
         qlast[qi] = gs_wave_max_i(Q[qi].last);
         rx0[qi] = (float)(tile_u * 16 + (q & 1) * 8) + 0.5f;
         ry0[qi] = (float)(tile_v * 16 + (q >> 1) * 8) + 0.5f;
@@ -200,8 +267,8 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
     for (int qi = 0; qi < NQ; ++qi) { pxq[qi] = rx0[qi] + (float)lx; pyq[qi] = ry0[qi] + (float)ly; }
 
     // entries at or beyond tile_last are dead for every pixel of the tile (RAST:609-610)
-    for (int hi = min(end, tile_last); hi > start; hi -= 64) {
-        const int lo = max(start, hi - 64);
+    for (int hi = min(seg_hi, tile_last); hi > seg_lo; hi -= 64) {
+        const int lo = max(seg_lo, hi - 64);
         const int i = lo + lane;
         const bool valid = i < hi;
         const int p = valid ? sorted_vals[i] : 0;
@@ -434,17 +501,24 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
             const int q = grp * NQ + qi;
             const int pu = tile_u * 16 + (q & 1) * 8 + lx_e, pv = tile_v * 16 + (q >> 1) * 8 + ly_e;
             if (pu >= W || pv >= H) continue;
+            if (COOP && coop.nseg > 1) {          // a segment's share: summed over the segments by the fold blocks of k_sum_rows
+                coop.mag_part[(size_t)coop.seg * 256 + grp * 64 + lane_e] = make_float2(Q[qi].tot0, Q[qi].tot1);
+                continue;
+            }
             const size_t o = (size_t)pv * (size_t)W + (size_t)pu;
             mag_image[2 * o] = Q[qi].tot0; mag_image[2 * o + 1] = Q[qi].tot1;
         }
     }
 }
 
-// One launch for the whole backward blend.  Workgroups of four waves: the first *n_heavy workgroups take one HEAVY tile each
-// (k_tile_order put those at the head of the order) and share it cooperatively, a quadrant per wave; every later workgroup
-// takes four (tile, quadrant group) work items of the ordinary kind -- NQ = 4: four tiles, one wave each; NQ = 2: two tiles,
-// two waves each; NQ = 1: one tile.  The grid is sized for the largest possible number of heavy tiles (the host does not know
-// n_heavy); surplus workgroups leave at once.
+// One launch for the whole backward blend.  Workgroups of four waves: the first n_items workgroups take one work item of a HEAVY
+// tile each (k_tile_order put those tiles at the head of the order and counted their items: a segment of the tile's cut list, or
+// the whole list) and share it cooperatively, a quadrant per wave; every later workgroup takes four (tile, quadrant group) work
+// items of the ordinary kind -- NQ = 4: four tiles, one wave each; NQ = 2: two tiles, two waves each; NQ = 1: one tile.  The grid
+// is sized for the largest possible number of heavy items (the host does not know it); surplus workgroups leave at once.
+#ifndef GS_HEAVY_ITEMS_LAST
+#define GS_HEAVY_ITEMS_LAST 0
+#endif
 #ifndef GS_BWD_MIN_WAVES
 #define GS_BWD_MIN_WAVES 4        // waves per SIMD the register allocator must leave room for (6 spills 17 registers: measured slower)
 #endif
@@ -458,7 +532,8 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
                                                         const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
                                                         const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
                                                         float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
-                                                        const uint8_t gen, float* __restrict__ mag_image)
+                                                        const uint8_t gen, float* __restrict__ mag_image,
+                                                        const float4* __restrict__ cuts, float2* __restrict__ cut_mag, const int32_t* __restrict__ tile_cut)
 {
     __shared__ float4 sRecAll[4][64][3];             // per wave: the batch's splat records (COOP: then the per-quadrant sums)
     __shared__ __attribute__((aligned(16))) float sRedAll[4][11 * RED_STRIDE];
@@ -466,16 +541,39 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
     __shared__ int32_t sSlot[64], sPoint[64], sTileLast[4];
     constexpr int G = 4 / NQ;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_heavy = *n_heavy_ptr;
+    const int n_heavy = n_heavy_ptr[0], n_items = n_heavy_ptr[1];
+    const int32_t* item_base = n_heavy_ptr + 4;
     BwdCoop coop;
     coop.done = sDone; coop.slot = sSlot; coop.point = sPoint; coop.tile_last = sTileLast;
     coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
-    if ((int)blockIdx.x < n_heavy) {
-        gs_bwd_tile_body<1, STRICT, true>(tile_order[blockIdx.x], wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
+    coop.seg = 0; coop.nseg = 1; coop.cut_rec = nullptr; coop.mag_part = nullptr;
+#if GS_HEAVY_ITEMS_LAST
+    // Dispatch order: the ordinary tiles first (heaviest first: long single-wave walks), the heavy tiles' items behind them -- a
+    // segment of 512 entries shared by four waves is a SHORT job, the kind that fills the end of a launch
+    const int light_groups = ((T - n_heavy) * G + 3) / 4;
+    const int hb = (int)blockIdx.x - light_groups;                     // index among the heavy items, if >= 0
+    const int lb = (int)blockIdx.x;
+#else
+    const int hb = (int)blockIdx.x < n_items ? (int)blockIdx.x : -1;
+    const int lb = (int)blockIdx.x - n_items;
+#endif
+    if (hb >= 0) {
+        if (hb >= n_items) return;
+        int h = 0;                                                     // the heavy tile that owns item hb: last h with item_base[h] <= hb
+        for (int step = HEAVY_CAP / 2; step > 0; step >>= 1)
+            if (h + step < n_heavy && item_base[h + step] <= hb) h += step;
+        const int tile = tile_order[h];
+        coop.nseg = item_base[h + 1] - item_base[h];
+        coop.seg = hb - item_base[h];
+        if (coop.nseg > 1) {
+            const size_t first = (size_t)(tile_cut[tile] - 1) * 256;
+            coop.cut_rec = cuts + first; coop.mag_part = cut_mag + first;
+        }
+        gs_bwd_tile_body<1, STRICT, true>(tile, wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
                                           PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
         return;
     }
-    const int item = ((int)blockIdx.x - n_heavy) * 4 + wave;          // work item among the ordinary (tile, quadrant group) pairs
+    const int item = lb * 4 + wave;                                    // work item among the ordinary (tile, quadrant group) pairs
     const int ti = n_heavy + item / G;
     if (ti >= T) return;
     gs_bwd_tile_body<NQ, STRICT, false>(tile_order[ti], item % G, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
@@ -489,10 +587,34 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
 // row, and two quad DPP steps fold the four partial sums.  A point with more rows is summed by its whole wave
 // (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the critical path.
 #define SUM_ROWS_SMALL 32
-__global__ __launch_bounds__(256) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
-                                                  const float* __restrict__ partial, const uint8_t* __restrict__ visited, const uint8_t* __restrict__ touched,
-                                                  const uint8_t gen, const float4* __restrict__ zero_row, float4* __restrict__ sums)
+struct GsMagFold { unsigned first_block; const int32_t* n_heavy; const int32_t* tile_order; const int32_t* tile_cut; const float2* cut_mag;
+                   float* mag_image; int W, H, tiles_x; };
+// fold blocks of k_sum_rows (behind the summing ones)
+__device__ __forceinline__ void gs_fold_mag(const GsMagFold& fold)
 {
+        // heavy tile h was walked in segments, each of which left its share of the pixels'
+        // sum |d uv| (RAST:666-667, 700-704) in the cut records' side array; one thread per pixel adds them up in segment order
+        const int h = (int)(blockIdx.x - fold.first_block);
+        if (!fold.mag_image || h >= fold.n_heavy[0]) return;
+        const int32_t* item_base = fold.n_heavy + 4;
+        const int nseg = item_base[h + 1] - item_base[h];
+        if (nseg <= 1) return;
+        const int tile = fold.tile_order[h];
+        const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int pu = (tile % fold.tiles_x) * 16 + (q & 1) * 8 + (lane & 7), pv = (tile / fold.tiles_x) * 16 + (q >> 1) * 8 + (lane >> 3);
+        if (pu >= fold.W || pv >= fold.H) return;
+        const float2* part = fold.cut_mag + (size_t)(fold.tile_cut[tile] - 1) * 256 + threadIdx.x;
+        float a = 0.0f, b = 0.0f;
+        for (int sgm = nseg - 1; sgm >= 0; --sgm) { const float2 v = part[(size_t)sgm * 256]; a += v.x; b += v.y; }   // back to front, like the walk
+        const size_t o = (size_t)pv * (size_t)fold.W + (size_t)pu;
+        fold.mag_image[2 * o] = a; fold.mag_image[2 * o + 1] = b;
+}
+
+__global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
+                                                  const float* __restrict__ partial, const uint8_t* __restrict__ visited, const uint8_t* __restrict__ touched,
+                                                  const uint8_t gen, const float4* __restrict__ zero_row, float4* __restrict__ sums, const GsMagFold fold)
+{
+    if (blockIdx.x >= fold.first_block) { gs_fold_mag(fold); return; }
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = t >> 2, q = t & 3;
     const int lane = threadIdx.x & 63;
@@ -843,13 +965,14 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
 {
     if (a.T > 0 && a.K > 0) {
         // (the `visited` / `touched` flags are not cleared per backward: a flag counts only if it holds THIS backward's tag, a.gen)
-        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint, a.n_heavy, a.split_heavy));
-        // workgroups: at most gs_heavy_cap(T) heavy tiles + the ordinary work items four to a workgroup
-        const unsigned groups = (unsigned)gs_heavy_cap(a.T) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
+        GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint, a.n_heavy, a.heavy_factor_x2,
+                                                                              a.tile_start, a.tile_end, a.cuts ? a.tile_cut : nullptr));
+        // workgroups: at most gs_item_cap(T) items of heavy tiles + the ordinary work items four to a workgroup
+        const unsigned groups = (unsigned)gs_item_cap(a.T) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
 #define GS_BWD_LAUNCH(NQ_, STRICT_)                                                                                                    \
         GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<groups, 256, 0, s>>>(a.tile_order, a.n_heavy, a.T, a.tile_start,  \
                  a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x,   \
-                 a.partial, a.visited, a.touched, a.gen, a.mag_image))
+                 a.partial, a.visited, a.touched, a.gen, a.mag_image, a.cuts, a.cut_mag, a.tile_cut))
         if (a.G == 1) { if (a.strict) GS_BWD_LAUNCH(4, true); else GS_BWD_LAUNCH(4, false); }
         else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true); else GS_BWD_LAUNCH(2, false); }
         else { if (a.strict) GS_BWD_LAUNCH(1, true); else GS_BWD_LAUNCH(1, false); }
@@ -857,9 +980,15 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);
-    if (a.M > 0 && a.T > 0 && a.K > 0)
-        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<(unsigned)(((size_t)a.M * 4 + 255) / 256), 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited, a.touched,
-                                                                                  a.gen, a.zero_row, a.sums));
+    if (a.M > 0 && a.T > 0 && a.K > 0) {
+        GsMagFold fold{};
+        fold.first_block = (unsigned)(((size_t)a.M * 4 + 255) / 256);
+        fold.n_heavy = a.n_heavy; fold.tile_order = a.tile_order; fold.tile_cut = a.tile_cut; fold.cut_mag = a.cut_mag;
+        fold.mag_image = a.cuts ? a.mag_image : nullptr; fold.W = a.W; fold.H = a.H; fold.tiles_x = a.tiles_x;
+        const unsigned fold_blocks = fold.mag_image ? (unsigned)gs_heavy_cap(a.T) : 0u;
+        GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<fold.first_block + fold_blocks, 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited, a.touched,
+                                                                                  a.gen, a.zero_row, a.sums, fold));
+    }
     else if (a.M > 0)
         (void)hipMemsetAsync(a.sums, 0, sizeof(float) * PW * (size_t)a.M, s);          // no pairs at all: every sum is zero
 }

@@ -17,6 +17,9 @@
 #ifndef GS_FWD_INT_MIN
 #define GS_FWD_INT_MIN 1
 #endif
+#ifndef GS_WORK_PER_BATCH
+#define GS_WORK_PER_BATCH 8      // a walked batch in units of (splat, quadrant) evaluations, for the tile ordering / heavy-tile choice
+#endif
 
 // find_tile_start_and_end (RAST:175-193) without a launch of its own: the first index of the sorted, compact keys
 // (tile << depth_bits | depth code) whose tile is >= `tile`, by a 64-ary search -- every step the wave's 64 lanes probe
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
                                                    float* __restrict__ image, float* __restrict__ depth_out,
                                                    float* __restrict__ acc_alpha, int32_t* __restrict__ last_out,
                                                    int32_t* __restrict__ count_out, int32_t* __restrict__ tile_work,
-                                                   const int32_t* __restrict__ order_hint)
+                                                   const int32_t* __restrict__ order_hint,
+                                                   float4* __restrict__ cuts, int32_t* __restrict__ tile_cut, int32_t* __restrict__ cut_alloc, int cut_cap)
 {
     __shared__ float4 sRec[4][64][3];          // the batch's splat records, one slab per wave
     const uint32_t K = min(ctr->K, K_cap);     // pairs of this frame, read on the device (gs_api.hip: predicted sizing)
@@ -76,13 +80,39 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
     const bool occupied = sRange[1] > sRange[0];
     const int start = occupied ? sRange[0] : 0, end = occupied ? sRange[1] : 0;
     if (threadIdx.x == 0) { tile_start[tile] = start; tile_end[tile] = end; }
+    // A LONG list (more than GS_CUT_MIN_LEN entries) is blended in SEGMENTS of GS_SEG entries: at every cut the colour gathered
+    // since the last cut is added to a running total and starts again from zero -- in every mode, so that the image does not
+    // depend on whether a backward is wanted (T, and with it every index, is untouched; a short list has no cut and its colour is
+    // the plain left-to-right sum as before).  When the frame is kept for a backward the cut is also RECORDED: each pixel's T at
+    // the cut and the colour of the segment that just ended (16 bytes), once more at the end of the walk -- the backward can
+    // then start anywhere in the list (k_backward.hip: heavy tiles are handed out segment by segment), and what it needs there,
+    // the colour BEHIND the cut, is a sum of later segments' colours: small terms added to small terms, as in the reference's own
+    // back-to-front accumulation (a difference of front sums would lose exactly the digits a dim pixel lives on).  Records are
+    // claimed with one atomic per long list; when the buffer is full the tile simply has none.
+    __shared__ int sCut;
+    const bool long_list = end - start > GS_CUT_MIN_LEN;                               // (workgroup-uniform)
+    int cut_base = -1;
+    if (!RGB_ONLY && cut_cap > 0 && long_list) {
+        if (threadIdx.x == 0) {
+            const int n_rec = (end - start - 1) / GS_SEG + 1;
+            int b = atomicAdd(cut_alloc, n_rec);
+            if (b + n_rec > cut_cap) b = -1;
+            sCut = b;
+            tile_cut[tile] = b + 1;
+        }
+        __syncthreads();
+        cut_base = sCut;
+    }
+    int next_rec = 0;                                                                  // cut records this wave has written
+    float tot_r = 0.0f, tot_g = 0.0f, tot_b = 0.0f;                                    // colour of the segments behind the last cut
 #ifdef GS_STATS
     const unsigned long long gs_t0 = wall_clock64();
 #endif
 
     float T_i = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, acc_d = 0.0f, norm = 0.0f;
     int last = start, count = 0;
-    int evals = 0;                 // splats that survived the cull in this quadrant (wave-uniform): what the backward will evaluate again
+    int evals = 0;                 // work the backward will repeat for this quadrant (wave-uniform): GS_WORK_PER_BATCH per 64-entry batch
+                                   // walked (index load, record gather, cull: latency a lone wave pays in full) + 1 per splat that survived the cull
     // a pixel of a partial edge tile that lies outside the image does not exist (extension; W,H % 16 == 0 in the reference)
     const bool inside = pixel_u < W && pixel_v < H;
     // Lane predicates live as wave-uniform 64-bit masks in SGPRs (votes fold into the v_cmp that made them, and
@@ -91,6 +121,12 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
 
     for (int base = start; base < end; base += 64) {
         if (alive == 0ull) break;
+        if (long_list && base > start && ((base - start) & (GS_SEG - 1)) == 0) {             // a cut: the state BEFORE entry `base`
+            if (cut_base >= 0) { cuts[(size_t)(cut_base + next_rec) * 256 + threadIdx.x] = make_float4(T_i, cr, cg, cb); next_rec += 1; }
+            tot_r += cr; tot_g += cg; tot_b += cb;
+            cr = 0.0f; cg = 0.0f; cb = 0.0f;
+        }
+        evals += GS_WORK_PER_BATCH;
         const int i = base + lane;
         const bool valid = i < end;
         const int p = valid ? sorted_vals[i] : 0;
@@ -174,6 +210,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
 #ifdef GS_STATS
     if (lane == 0 && blockIdx.x * 4 + wave < 65536) { gs_stats_wave_times[2 * (blockIdx.x * 4 + wave)] = gs_t0; gs_stats_wave_times[2 * (blockIdx.x * 4 + wave) + 1] = wall_clock64(); }
 #endif
+    if (cut_base >= 0) {
+        // a wave that stopped early (every pixel saturated) leaves the cuts it never reached as empty segments; the colour gathered
+        // since its last cut belongs to the last record, which also carries the final T
+        const int n_rec = (end - start - 1) / GS_SEG + 1;
+        for (int k = next_rec; k < n_rec - 1; ++k) cuts[(size_t)(cut_base + k) * 256 + threadIdx.x] = make_float4(T_i, 0.0f, 0.0f, 0.0f);
+        cuts[(size_t)(cut_base + n_rec - 1) * 256 + threadIdx.x] = make_float4(T_i, cr, cg, cb);
+    }
+    cr += tot_r; cg += tot_g; cb += tot_b;          // (exact for a list without cuts: the totals are zero)
     if (!inside) return;
     const size_t o = (size_t)pixel_v * (size_t)W + (size_t)pixel_u;
     image[3 * o] = cr; image[3 * o + 1] = cg; image[3 * o + 2] = cb;
@@ -182,8 +226,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
         acc_alpha[o] = 1.0f - T_i;
         last_out[o] = last;
         count_out[o] = count;
-        // (splat, quadrant) evaluations of this tile: the backward repeats them (same cull, same stop), so their number
-        // predicts its cost per tile far better than the list length does.  Scheduling hint only.
+        // work of this tile in (splat, quadrant) evaluations, batches included: the backward repeats it (same cull, same stop), so it
+        // predicts the backward's cost per tile far better than the list length does.  Scheduling hint only.
         if (lane == 0 && evals > 0) atomicAdd(&tile_work[tile], evals);
     }
 }
@@ -193,8 +237,8 @@ void gs_launch_blend_fwd(const GsBlendFwdArgs& a, hipStream_t s)
     if (a.T <= 0) return;
     if (a.rgb_only)
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<true><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.counters, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
-                                                                             a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
+                                                                             a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint, a.cuts, a.tile_cut, a.cut_alloc, a.cut_cap));
     else
         GS_TIMED(a.prof, KID_BLEND_FWD, s, k_blend_fwd<false><<<a.T, 256, 0, s>>>(a.tile_start, a.tile_end, a.keys_sorted, a.key64, a.depth_bits, a.counters, a.K, a.vals_sorted, a.PA, a.PB, a.PC, a.W, a.H,
-                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint));
+                                                                              a.tiles_x, a.image, a.depth, a.acc_alpha, a.last, a.count, a.tile_work, a.order_hint, a.cuts, a.tile_cut, a.cut_alloc, a.cut_cap));
 }

@@ -670,6 +670,33 @@ def test_heavy_tiles_shared_by_four_waves_clustered_scene(P):
         lens = f.tile_points_end - f.tile_points_start
         assert lens.max() > 8 * lens.mean(), (lens.max(), lens.mean())
         assert module.last_frame.heavy_tiles() > 0, waves
+        tiles, items = module.last_frame.heavy_tiles(), module.last_frame.heavy_tiles(items=True)
+        if w * h < 1000 * 600:      # small image: the ordinary waves do not fill the chip, so the forward cut the long lists and the
+            if lens.max() > 2048:   # heavy tiles are walked in 512-entry segments (gs_api.hip: want_cuts)
+                assert items > tiles, (waves, tiles, items)
+        else:                       # large image: one work item per heavy tile
+            assert items == tiles, (waves, tiles, items)
+
+
+def test_heavy_tiles_in_segments_very_long_lists(P):
+    """Lists of several thousand entries on a small image (every tile heavy by any measure, the heaviest far beyond the rest): the
+    forward stores each pixel's T and accumulated colour every 512 entries of a long list, and the backward hands a heavy tile out
+    as one work item per segment, each starting from the record of its cut (k_backward.hip: BwdCoop.seg) -- including the pixels'
+    sum |d uv| (magnitude_grad_viewspace_on_image), which the segments leave as partial sums.  Same bars against the oracle; the
+    result must not depend on whether the list was cut (GS_BWD_SEGMENTS=0 is covered by the suite run under that switch)."""
+    rng = np.random.default_rng(88)
+    s = synth(26000, 208, 160, 0.02, sh_deg=3, seed=88)
+    # 6000 translucent splats piled on a corner region: lists of thousands of entries there, a few hundred elsewhere
+    s.point_cloud[:6000, 0] = rng.uniform(-0.9, -0.4, 6000).astype(np.float32) * s.point_cloud[:6000, 2] / 1.2
+    s.point_cloud[:6000, 1] = rng.uniform(-0.7, -0.3, 6000).astype(np.float32) * s.point_cloud[:6000, 2] / 1.2
+    s.point_cloud_features[:6000, 4:7] = np.log(rng.uniform(0.05, 0.15, (6000, 3))).astype(np.float32)
+    s.point_cloud_features[:6000, 7] = rng.uniform(-5.0, -2.5, 6000).astype(np.float32)
+    q, t = view_pose()
+    module, inp, f, b, got = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=11)
+    lens = f.tile_points_end - f.tile_points_start
+    assert lens.max() > 3000, lens.max()
+    fr = module.last_frame
+    assert fr.heavy_tiles() > 0 and fr.heavy_tiles(items=True) >= fr.heavy_tiles() + 4, (fr.heavy_tiles(), fr.heavy_tiles(items=True))
 
 
 def test_flag_tags_wrap_round_after_255_backwards(P):

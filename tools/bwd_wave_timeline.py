@@ -32,16 +32,21 @@ torch.cuda.synchronize()
 T = ((s.height + 15) // 16) * ((s.width + 15) // 16)
 G = int(os.environ.get("GS_BWD_WAVES_PER_TILE", 0)) or (4 if T < 2000 else 2 if T < 6144 else 1)     # gs_api.hip: waves_per_tile
 n_heavy = module.last_frame.heavy_tiles()
-# one record per wave, indexed by workgroup * 4 + wave: the heavy tiles' workgroups first, then the ordinary work items four
-# to a workgroup (k_backward.hip: k_blend_bwd_tile)
-nrec = min(4 * (n_heavy + (T * G - n_heavy * G + 3) // 4), 65536)
+n_items = module.last_frame.heavy_tiles(items=True)
+# one record per wave, indexed by workgroup * 4 + wave: the heavy tiles' work items first (one workgroup each: a 512-entry segment of
+# a cut list, or a whole list), then the ordinary work items four to a workgroup (k_backward.hip: k_blend_bwd_tile)
+nrec = min(4 * (n_items + ((T - n_heavy) * G + 3) // 4), 65536)
 buf = (C.c_ulonglong * (2 * nrec))()
 _native.lib().gs_debug_wave_times_read(buf, nrec)
 a = np.array(buf, dtype=np.uint64).reshape(nrec, 2).astype(np.int64)
-a = a[a[:, 1] > a[:, 0]]
-a = a[a[:, 1] > np.percentile(a[:, 0], 10)]        # (a wave that left at once wrote nothing: its slot still holds a stamp of the forward blend, which ended before this launch began)
+idx = np.arange(a.shape[0])
+keep = a[:, 1] > a[:, 0]
+a, idx = a[keep], idx[keep]
+keep = a[:, 1] > np.percentile(a[:, 0], 10)
+a, idx = a[keep], idx[keep]        # (a wave that left at once wrote nothing: its slot still holds a stamp of the forward blend, which ended before this launch began)
 T = a.shape[0]
-print(f"{wl}: {n_heavy} heavy tiles (4 cooperating waves each), {G} wave(s) per ordinary tile")
+print(f"{wl}: {n_heavy} heavy tiles handed out as {n_items} work items (4 cooperating waves each), {G} wave(s) per ordinary tile")
+heavy_waves = 4 * n_items
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0).astype(float), (a[:, 1] - t0).astype(float)      # wall-clock ticks (only ratios are used)
 dur = en - st
@@ -61,3 +66,8 @@ for d in range(10):
     print(f"  {d}: start {st[sl].mean() / span:5.2f}  dur {dur[sl].mean() / span:5.2f}  max end {en[sl].max() / span:5.2f}")
 longest = np.argsort(dur)[-8:]
 print("longest waves: block ids", longest, "durations/span", np.round(dur[longest] / span, 2), "start/span", np.round(st[longest] / span, 2))
+
+hv = idx < heavy_waves
+if hv.any() and (~hv).any():
+    print(f"heavy items: {hv.sum()} waves, duration mean {dur[hv].mean() / 100:.1f} us max {dur[hv].max() / 100:.1f}, last end {en[hv].max() / span:.2f} of the span; "
+          f"ordinary: {(~hv).sum()} waves, mean {dur[~hv].mean() / 100:.1f} us max {dur[~hv].max() / 100:.1f}, last end {en[~hv].max() / span:.2f}")

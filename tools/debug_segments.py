@@ -1,0 +1,31 @@
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import parity_util as P
+from oracle import oracle
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 60163
+c = P.soak_case(seed)
+s, q, t, partial, rng = c["scene"], c["q"], c["t"], c["partial"], c["rng"]
+unit = dict(grad_color_factor=1.0, grad_high_order_color_factor=1.0, grad_s_factor=1.0, grad_q_factor=1.0, grad_alpha_factor=1.0)
+ocfg = oracle.default_config(allow_partial_tiles=int(partial), **unit)
+f, feat_after = P.run_oracle(s, q, t, ocfg)
+cfg = P.Rast.GaussianPointCloudRasterisationConfig(); cfg.allow_partial_tiles = partial
+for k, v in unit.items(): setattr(cfg, k, v)
+got = {}
+module = P.Rast(cfg, backward_valid_point_hook=lambda x: got.setdefault("hook", x))
+inp = P.make_input(s, q, t, 3)
+image = module(inp)[0]
+target = torch.tensor(rng.uniform(0, 1, image.shape).astype(np.float32), device=image.device)
+g = 2.0 * (image.detach() - target)
+image.backward(g)
+fr = module.last_frame
+lens = f.tile_points_end - f.tile_points_start
+print("W,H", c["W"], c["H"], "T", lens.size, "lens max", lens.max(), "heavy", fr.heavy_tiles(), "items", fr.heavy_tiles(items=True), "segments env", os.environ.get("GS_BWD_SEGMENTS"))
+b = oracle.backward(f, g.cpu().numpy(), 3, ocfg, want_summed=True)
+gp, gf = inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()
+m = P.backward_margins(gp, gf, b)
+print({k: (round(v["bar_use_max"], 2), "%.1e" % P.rel_err(gp if k == "xyz" else gf[:, dict(q=(0,4),s=(4,7),opacity=(7,8),sh=(8,56))[k][0]:dict(q=(0,4),s=(4,7),opacity=(7,8),sh=(8,56))[k][1]], b["grad_pointcloud"] if k == "xyz" else b["grad_pointcloud_features"][:, dict(q=(0,4),s=(4,7),opacity=(7,8),sh=(8,56))[k][0]:dict(q=(0,4),s=(4,7),opacity=(7,8),sh=(8,56))[k][1]])) for k, v in m.items()})
+mi = module.last_backward_extras["magnitude_grad_viewspace_on_image"].cpu().numpy()
+print("mag image rel err", P.rel_err(mi, b["magnitude_grad_viewspace_on_image"]))
+np.save(os.path.join(ROOT, "gpurun_out", f"dbg_gp_{os.environ.get('GS_BWD_SEGMENTS','1')}.npy"), gp)
