@@ -461,7 +461,9 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     const bool want_cuts = seg_env >= 0 ? seg_env == 1 : (int64_t)T * waves_per_tile(T) < 6144;
     int cut_cap = 0;
     if (want_cuts && f->info.kept_for_backward && !cfg->rgb_only && K_bound > 0) {
-        cut_cap = (int)std::max<uint64_t>(4096, (uint64_t)K_bound / 2048);
+        // every long list can have its records: sum over lists of ((L - 1) / GS_SEG + 1) <= K / GS_SEG + T.  (A capacity that could run
+        // out would make WHICH lists get cuts depend on the order of the claims, and with it the last bits of the gradients.)
+        cut_cap = (int)std::min<uint64_t>((uint64_t)K_bound / GS_SEG + (uint64_t)T + 2, 0x7fffffffu);
         ENSURE(B.cuts, (size_t)cut_cap * 256 * sizeof(float4)); ENSURE(B.cut_mag, (size_t)cut_cap * 256 * sizeof(float2));
     }
     f->cut_cap = cut_cap;
@@ -876,6 +878,7 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.G = G;
     a.n_heavy = B.tile_order.as<int32_t>() + f->info.n_tiles;
     a.cuts = f->cut_cap > 0 ? B.cuts.as<float4>() : nullptr; a.cut_mag = B.cut_mag.as<float2>();
+    a.item_cap = f->cut_cap;                          // >= the segments of all heavy tiles together (never binds: deterministic)
     a.tile_cut = B.tile_start.as<int32_t>() + 3 * (size_t)f->info.n_tiles;
     // heavy-tile threshold in half-means of work: sharing a tile among four waves costs more work in total and shortens the launch
     // only where long walks are what the launch waits for; twice the mean measured best on both clustered workloads and changes
@@ -1076,7 +1079,7 @@ extern "C" int gs_frame_heavy_tiles(gs_ctx* c, const gs_frame* h, int32_t* n_out
     std::lock_guard<std::mutex> lock(c->mu);
     Frame* f = resolve(c, h);
     if (!f || !f->bufs) return fail(GS_ERR_STATE, "gs_frame_heavy_tiles: not a live frame of this context");
-    if (!(f->info.stages & GS_STAGE_RASTER) || f->info.n_tiles <= 0 || !f->bufs->tile_order.p) { n_out[0] = n_out[1] = 0; return GS_OK; }
+    if (!(f->info.stages & GS_STAGE_RASTER) || f->info.n_tiles <= 0 || f->info.n_keys <= 0 || !f->bufs->tile_order.p) { n_out[0] = n_out[1] = 0; return GS_OK; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     HIP_TRY(enter_stream(c, s));

@@ -48,7 +48,6 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #define GS_SEG 512
 #define GS_CUT_MIN_LEN 1024
 #define GS_HEAVY_CAP 1024            // most tiles a backward treats as heavy
-#define GS_ITEM_CAP 4096             // most (heavy tile, segment) work items of a backward
 // tile arrays of a frame, cleared by its first kernel: tile_start | tile_end | tile_work | tile_cut (first cut record + 1, 0 = none) | cut_alloc
 #define GS_TILE_INTS(T) (4 * (size_t)(T) + 4)
 // tile_order buffer: order (T) | n_heavy | n_items | pad pad | item_base (GS_HEAVY_CAP + 1)
@@ -302,6 +301,7 @@ struct GsBackwardArgs {
     int G;                          // waves per tile in k_blend_bwd_tile (1, 2 or 4) = rows of `partial` per (point, tile) pair
     int32_t* n_heavy;               // device: number of heavy tiles at the head of tile_order (k_tile_order -> k_blend_bwd_tile); n_items and item_base follow it
     const float4* cuts; float2* cut_mag; const int32_t* tile_cut;    // list cuts of the forward (NULL: none), per-segment |d uv| partial sums
+    int item_cap;                   // work items of heavy tiles the launch has room for when there are cuts
     int heavy_factor_x2;            // a tile is heavy from this many half-means of work on; 0: no tile is (GS_BWD_SPLIT_HEAVY=0)
     int strict;                     // gs_config.bwd_reference_order: loop 1's UTIL:331-348 in the reference's own operation order
     float* partial;                 // (K*G,12) per (point,tile[,quadrant group]) sums in slot order

@@ -52,11 +52,10 @@ __host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? 
 // A heavy tile whose list the forward CUT (k_blend_fwd: every GS_SEG entries each pixel's T and accumulated colour) is handed out
 // as one work item per segment: item_base[h] .. item_base[h + 1] are the items of heavy tile h (n_heavy_out[1] = their number,
 // n_heavy_out[4 ..] = item_base).  A heavy tile without cuts is one item.
-__host__ __device__ inline int gs_item_cap(int T) { const int c = 4 * T; return c < GS_ITEM_CAP ? c : GS_ITEM_CAP; }
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,
                                                      int32_t* __restrict__ n_heavy_out, int heavy_factor_x2,
                                                      const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
-                                                     const int32_t* __restrict__ tile_cut)
+                                                     const int32_t* __restrict__ tile_cut, int item_cap)
 {
     __shared__ uint32_t bins[ORDER_BINS];
     __shared__ int32_t sHeavy[HEAVY_CAP];
@@ -108,8 +107,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
         if (bw > ORDER_BINS - 1) bw = ORDER_BINS - 1;                                       // (everything beyond the last bin edge shares it)
         int n = 0;
         if (heavy_factor_x2 > 0) n = (int)bins[ORDER_BINS - (int)bw];                               // start of the heaviest light bin = number of heavier tiles
+        // at most gs_heavy_cap(T) of them, and always WHOLE bins: which tiles of a bin come first in the order is up to the LDS atomics
+        // below, and a heavy tile's sums are added up in another order than an ordinary one's -- the set must not depend on that
         const int cap = gs_heavy_cap(T);
-        sNHeavy = n < cap ? n : cap;
+        if (n > cap) {
+            int lo = 0, hi = ORDER_BINS - (int)bw;                       // bins[] is the exclusive scan: bins[k] = tiles in bins < k
+            while (lo < hi) { const int mid = (lo + hi + 1) / 2; if ((int)bins[mid] <= cap) lo = mid; else hi = mid - 1; }
+            n = (int)bins[lo];
+        }
+        sNHeavy = n;
         *n_heavy_out = sNHeavy;
     }
     __syncthreads();
@@ -152,8 +158,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     };
     uint32_t ibase = 0, total_items = 0;
     block_scan((uint32_t)nseg, ibase, total_items);
-    const int cap = gs_item_cap(T);
-    if (t < n_heavy && (int)(ibase + (uint32_t)nseg) + (n_heavy - 1 - t) > cap) nseg = 1;
+    if (t < n_heavy && (int)(ibase + (uint32_t)nseg) + (n_heavy - 1 - t) > item_cap) nseg = 1;     // (never with the host's capacity: see gs_api.hip)
     block_scan((uint32_t)nseg, ibase, total_items);
     if (t < n_heavy) n_heavy_out[4 + t] = (int32_t)ibase;
     if (t == 0) { n_heavy_out[4 + n_heavy] = (int32_t)total_items; n_heavy_out[1] = (int32_t)total_items; }
@@ -966,9 +971,9 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
     if (a.T > 0 && a.K > 0) {
         // (the `visited` / `touched` flags are not cleared per backward: a flag counts only if it holds THIS backward's tag, a.gen)
         GS_TIMED(a.prof, KID_TILE_ORDER, s, k_tile_order<<<1, 1024, 0, s>>>(a.tile_work, a.T, a.tile_order, a.order_hint, a.n_heavy, a.heavy_factor_x2,
-                                                                              a.tile_start, a.tile_end, a.cuts ? a.tile_cut : nullptr));
-        // workgroups: at most gs_item_cap(T) items of heavy tiles + the ordinary work items four to a workgroup
-        const unsigned groups = (unsigned)gs_item_cap(a.T) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
+                                                                              a.tile_start, a.tile_end, a.cuts ? a.tile_cut : nullptr, a.cuts ? a.item_cap : gs_heavy_cap(a.T)));
+        // workgroups: room for every segment of every heavy tile (no cuts: one item per heavy tile) + the ordinary work items four to a workgroup
+        const unsigned groups = (unsigned)(a.cuts ? a.item_cap : gs_heavy_cap(a.T)) + (unsigned)(((size_t)a.T * (size_t)a.G + 3) / 4);
 #define GS_BWD_LAUNCH(NQ_, STRICT_)                                                                                                    \
         GS_TIMED(a.prof, KID_BLEND_BWD, s, k_blend_bwd_tile<NQ_, STRICT_><<<groups, 256, 0, s>>>(a.tile_order, a.n_heavy, a.T, a.tile_start,  \
                  a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H, a.tiles_x,   \

@@ -723,3 +723,26 @@ def test_flag_tags_wrap_round_after_255_backwards(P):
         if it in (253, 254, 255, 256, 257, 258, 509, 510, 511, 512) or it % 50 == 0:
             assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), it
             assert np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)), it
+
+
+def test_heavy_set_and_cuts_do_not_depend_on_claim_order(P):
+    """Soak seed 400829 (round 3): a small image whose heavy tiles outnumber the cap and whose long lists need more cut records than
+    a fixed buffer held -- which tiles were heavy / cut then depended on the order of LDS and global atomics, and with it the last
+    bits of the gradients (a heavy tile's sums are added in another order than an ordinary one's).  The heavy set is whole bins of
+    the work histogram now and every long list gets its records: the same frame rendered three times on one context (exact sizes,
+    then predicted ones, which change every capacity) gives the same bits."""
+    c = P.soak_case(400829)
+    s, q, t, band, partial = c["scene"], c["q"], c["t"], c["band"], c["partial"]
+    cfg = P.Rast.GaussianPointCloudRasterisationConfig()
+    cfg.allow_partial_tiles = partial
+    module = P.Rast(cfg)
+    runs = []
+    for _ in range(3):
+        inp = P.make_input(s, q, t, band)
+        img = module(inp)[0]
+        (img * img).sum().backward()
+        runs.append((module.last_frame.sizing, img.detach().cpu().numpy(), inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()))
+    assert [r[0] for r in runs] == ["exact", "predicted", "predicted"]
+    for r in runs[1:]:
+        for a, b in zip(r[1:], runs[0][1:]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
