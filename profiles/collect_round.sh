@@ -27,6 +27,8 @@ python3 bench.py --workload cfg3_1080p --no-cpu-baseline > $R/${TAG}_bench_cfg3_
 for wl in cfg3_clustered cfg2_clustered; do
   python3 bench.py --workload $wl --no-cpu-baseline > $R/${TAG}_bench_$wl.json 2>> $E
   GS_BWD_SPLIT_HEAVY=0 python3 bench.py --workload $wl --no-cpu-baseline > $R/${TAG}_bench_${wl}_no_heavy_sharing.json 2>> $E
+  GS_BWD_SEGMENTS=0 python3 bench.py --workload $wl --no-cpu-baseline > $R/${TAG}_bench_${wl}_no_segments.json 2>> $E
+  GS_BWD_SEGMENTS=1 python3 bench.py --workload $wl --no-cpu-baseline > $R/${TAG}_bench_${wl}_segments.json 2>> $E
 done
 echo "bench lines done" >&2
 rm -rf gpurun_out/prof_${TAG}

@@ -37,7 +37,7 @@
 // Tiles in order of decreasing backward work (entries to walk), so that the heaviest tiles are
 // dispatched first and the launch does not end on a few long-running waves.  Counting sort in one
 // workgroup: 2048 bins of width ORDER_BIN_WIDTH (more work shares the first bin).  Pure scheduling: results do
-// not depend on it.  Work = the (splat, quadrant) evaluations the forward counted for the tile.
+// not depend on it.  Work = what the forward counted for the tile: 8 per walked batch + 1 per (splat, quadrant) evaluation.
 #define ORDER_BINS 2048
 #define ORDER_BIN_WIDTH 4
 #define ORDER_PER 8
@@ -45,11 +45,12 @@
 // choice: twice the mean) and at least HEAVY_MIN_WORK evaluations (at most T / 8 of them, HEAVY_CAP in all).  k_blend_bwd_tile gives each of them a whole
 // workgroup (four cooperating waves, one per quadrant) instead of one wave: on a clustered scene a few tiles carry lists
 // ten to twenty times the mean and their single waves ARE the launch (profiles/r03_*_wave_timeline*.txt); on the uniform
-// generator (max / mean = 2) there are none.  Scheduling only, like the order itself.
+// generator (max / mean = 2) there are none.  Which tiles are heavy changes the ORDER in which a pair's contributions are added
+// (quadrant sums, then their sum), hence the set is whole bins of the histogram: a deterministic function of the work counts.
 #define HEAVY_MIN_WORK 1024
 #define HEAVY_CAP GS_HEAVY_CAP
 __host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? T / 8 : HEAVY_CAP; }
-// A heavy tile whose list the forward CUT (k_blend_fwd: every GS_SEG entries each pixel's T and accumulated colour) is handed out
+// A heavy tile whose list the forward CUT (k_blend_fwd: every GS_SEG entries each pixel's T and the colour since the last cut) is handed out
 // as one work item per segment: item_base[h] .. item_base[h + 1] are the items of heavy tile h (n_heavy_out[1] = their number,
 // n_heavy_out[4 ..] = item_base).  A heavy tile without cuts is one item.
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_work, int T, int32_t* __restrict__ order, int32_t* __restrict__ hint,

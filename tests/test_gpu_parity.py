@@ -659,7 +659,7 @@ def test_predicted_sizing_and_its_redo_change_nothing(P):
 
 def test_heavy_tiles_shared_by_four_waves_clustered_scene(P):
     """A heavy-tailed scene (synthetic.synth_clustered: an object that fills a tenth of the image with translucent splats, a
-    sparse shell, a few huge floaters): the tiles whose work is three times the mean or more get a whole workgroup in the backward
+    sparse shell, a few huge floaters): the tiles whose work is twice the mean or more get a whole workgroup in the backward
     blend -- four waves, a quadrant each, their per-splat sums added up in LDS before the pair's one row is stored
     (k_backward.hip: COOP).  Same bars against the oracle as everywhere; and the count of such tiles is not zero here."""
     from taichi_3d_gaussian_splatting_amd.synthetic import synth_clustered
@@ -669,6 +669,9 @@ def test_heavy_tiles_shared_by_four_waves_clustered_scene(P):
         module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=9)
         lens = f.tile_points_end - f.tile_points_start
         assert lens.max() > 8 * lens.mean(), (lens.max(), lens.mean())
+        import os
+        if any(k in os.environ for k in ("GS_BWD_SPLIT_HEAVY", "GS_BWD_SEGMENTS", "GS_BWD_HEAVY_X2")):
+            continue                # the suite is also run under the library's diagnostic switches: the policy below is then not the default one
         assert module.last_frame.heavy_tiles() > 0, waves
         tiles, items = module.last_frame.heavy_tiles(), module.last_frame.heavy_tiles(items=True)
         if w * h < 1000 * 600:      # small image: the ordinary waves do not fill the chip, so the forward cut the long lists and the
@@ -696,7 +699,9 @@ def test_heavy_tiles_in_segments_very_long_lists(P):
     lens = f.tile_points_end - f.tile_points_start
     assert lens.max() > 3000, lens.max()
     fr = module.last_frame
-    assert fr.heavy_tiles() > 0 and fr.heavy_tiles(items=True) >= fr.heavy_tiles() + 4, (fr.heavy_tiles(), fr.heavy_tiles(items=True))
+    import os
+    if not any(k in os.environ for k in ("GS_BWD_SPLIT_HEAVY", "GS_BWD_SEGMENTS", "GS_BWD_HEAVY_X2")):
+        assert fr.heavy_tiles() > 0 and fr.heavy_tiles(items=True) >= fr.heavy_tiles() + 4, (fr.heavy_tiles(), fr.heavy_tiles(items=True))
 
 
 def test_flag_tags_wrap_round_after_255_backwards(P):
@@ -742,7 +747,9 @@ def test_heavy_set_and_cuts_do_not_depend_on_claim_order(P):
         img = module(inp)[0]
         (img * img).sum().backward()
         runs.append((module.last_frame.sizing, img.detach().cpu().numpy(), inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy()))
-    assert [r[0] for r in runs] == ["exact", "predicted", "predicted"]
+    import os
+    if "GS_PREDICT_SIZES" not in os.environ:
+        assert [r[0] for r in runs] == ["exact", "predicted", "predicted"]
     for r in runs[1:]:
         for a, b in zip(r[1:], runs[0][1:]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
