@@ -452,8 +452,7 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
                             int H, int W, int tiles_x, int T, const gs_config* cfg, const gs_forward_out* out, hipStream_t s, bool publish)
 {
     FrameBufs& B = *f->bufs;
-    // list cuts for the backward's heavy tiles (k_blend_fwd): only a frame that will be back-propagated wants them.  Records are
-    // claimed per long list; a full buffer just means fewer tiles with cuts, never an error.
+    // list cuts for the backward's heavy tiles (k_blend_fwd): only a frame that will be back-propagated wants them.
     // Policy (measured): segments pay where the ordinary waves do not fill the chip anyway (T * G waves for 5120
     // slots: cfg2_clustered 0.38 -> 0.22 ms) and cost where they do (cfg3_clustered 0.31 -> 0.34 ms: more, shorter work items in a
     // launch that was already full).  GS_BWD_SEGMENTS=0 / 1 forces never / always.

@@ -522,9 +522,6 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
 // the whole list) and share it cooperatively, a quadrant per wave; every later workgroup takes four (tile, quadrant group) work
 // items of the ordinary kind -- NQ = 4: four tiles, one wave each; NQ = 2: two tiles, two waves each; NQ = 1: one tile.  The grid
 // is sized for the largest possible number of heavy items (the host does not know it); surplus workgroups leave at once.
-#ifndef GS_HEAVY_ITEMS_LAST
-#define GS_HEAVY_ITEMS_LAST 0
-#endif
 #ifndef GS_BWD_MIN_WAVES
 #define GS_BWD_MIN_WAVES 4        // waves per SIMD the register allocator must leave room for (6 spills 17 registers: measured slower)
 #endif
@@ -553,18 +550,10 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
     coop.done = sDone; coop.slot = sSlot; coop.point = sPoint; coop.tile_last = sTileLast;
     coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
     coop.seg = 0; coop.nseg = 1; coop.cut_rec = nullptr; coop.mag_part = nullptr;
-#if GS_HEAVY_ITEMS_LAST
-    // Dispatch order: the ordinary tiles first (heaviest first: long single-wave walks), the heavy tiles' items behind them -- a
-    // segment of 512 entries shared by four waves is a SHORT job, the kind that fills the end of a launch
-    const int light_groups = ((T - n_heavy) * G + 3) / 4;
-    const int hb = (int)blockIdx.x - light_groups;                     // index among the heavy items, if >= 0
-    const int lb = (int)blockIdx.x;
-#else
+    // (heavy items first: handing them out BEHIND the ordinary tiles, as the short jobs they are, measured slower -- DESIGN.md section 5)
     const int hb = (int)blockIdx.x < n_items ? (int)blockIdx.x : -1;
     const int lb = (int)blockIdx.x - n_items;
-#endif
     if (hb >= 0) {
-        if (hb >= n_items) return;
         int h = 0;                                                     // the heavy tile that owns item hb: last h with item_base[h] <= hb
         for (int step = HEAVY_CAP / 2; step > 0; step >>= 1)
             if (h + step < n_heavy && item_base[h + step] <= hb) h += step;
