@@ -753,3 +753,28 @@ def test_heavy_set_and_cuts_do_not_depend_on_claim_order(P):
     for r in runs[1:]:
         for a, b in zip(r[1:], runs[0][1:]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_second_backward_through_a_frame_with_cut_lists(P):
+    """backward(retain_graph=True) twice on a frame whose heavy tiles are walked in segments: the forward's cut records are read-only
+    for the backward and the segments' partial sums are rewritten with the same values, so the second pass adds exactly the same
+    gradient again (autograd accumulates: 2x, an exact doubling) and the hook's per-pixel magnitudes are the same bits."""
+    rng = np.random.default_rng(88)
+    s = synth(26000, 208, 160, 0.02, sh_deg=3, seed=88)
+    s.point_cloud[:6000, 0] = rng.uniform(-0.9, -0.4, 6000).astype(np.float32) * s.point_cloud[:6000, 2] / 1.2
+    s.point_cloud[:6000, 1] = rng.uniform(-0.7, -0.3, 6000).astype(np.float32) * s.point_cloud[:6000, 2] / 1.2
+    s.point_cloud_features[:6000, 4:7] = np.log(rng.uniform(0.05, 0.15, (6000, 3))).astype(np.float32)
+    s.point_cloud_features[:6000, 7] = rng.uniform(-5.0, -2.5, 6000).astype(np.float32)
+    q, t = view_pose()
+    mags = []
+    module = P.Rast(P.Rast.GaussianPointCloudRasterisationConfig(), backward_valid_point_hook=lambda x: mags.append(x.magnitude_grad_viewspace_on_image.cpu().numpy().copy()))
+    inp = P.make_input(s, q, t, 3)
+    image = module(inp)[0]
+    g = 2.0 * (image.detach() - 0.5)
+    image.backward(g, retain_graph=True)
+    first = (inp.point_cloud.grad.cpu().numpy().copy(), inp.point_cloud_features.grad.cpu().numpy().copy())
+    image.backward(g)
+    second = (inp.point_cloud.grad.cpu().numpy(), inp.point_cloud_features.grad.cpu().numpy())
+    for a, b in zip(first, second):
+        assert np.array_equal((2.0 * a).view(np.uint32), b.view(np.uint32))
+    assert len(mags) == 2 and np.array_equal(mags[0].view(np.uint32), mags[1].view(np.uint32))
