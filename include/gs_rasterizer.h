@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 #define GS_TILE 16              /* RAST:27-28 TILE_WIDTH = TILE_HEIGHT */
 #define GS_FEATURES 56          /* RAST:208-236 row layout */
 
@@ -286,6 +286,26 @@ int gs_backward_shard(gs_ctx* ctx, gs_frame* frame, const gs_scene* shard, const
  * LossFunction.py:40-51 is not part of this call. */
 int gs_loss_l1_ssim(gs_ctx* ctx, const float* predicted_image, const float* ground_truth_image, int32_t height, int32_t width,
                     float lambda_value, float* loss_terms, float* grad_predicted, gs_stream stream);
+
+/* The same loss as two calls, for an autograd node (forward now, gradient when and if backward runs) and for images that are not
+ * contiguous (3,H,W) arrays: an image is described by its base pointer and the strides, in floats, of (channel, row, column)
+ * -- {H*W, W, 1} for a contiguous (3,H,W) array, {1, 3*W, 3} for the rasteriser's (H,W,3) output read in place, which saves
+ * the permuted copy GaussianPointTrainer.py:173 makes.  clamp_predicted != 0 applies torch.clamp(., 0, 1) to the predicted
+ * image on the fly (same line of the trainer): same value, and a gradient of zero where the raw value lies outside [0, 1].
+ * gs_loss_maps_floats(H, W) floats of device memory, owned by the caller, carry the forward's derivative maps to the backward. */
+typedef struct gs_loss_image {
+    const float* data;
+    int64_t stride_channel, stride_row, stride_column;
+} gs_loss_image;
+int64_t gs_loss_maps_floats(int32_t height, int32_t width);
+int gs_loss_l1_ssim_forward(gs_ctx* ctx, const gs_loss_image* predicted_image, const gs_loss_image* ground_truth_image,
+                            int32_t height, int32_t width, int32_t clamp_predicted, float lambda_value,
+                            float* maps, float* loss_terms, gs_stream stream);
+/* upstream: device scalar d(final loss)/dL, or NULL for 1.  grad_predicted: where to write d/d predicted_image, with its own
+ * strides (data is written despite the const of the shared struct). */
+int gs_loss_l1_ssim_backward(gs_ctx* ctx, const gs_loss_image* predicted_image, const gs_loss_image* ground_truth_image,
+                             int32_t height, int32_t width, int32_t clamp_predicted, float lambda_value,
+                             const float* maps, const float* upstream, const gs_loss_image* grad_predicted, gs_stream stream);
 
 /* Scale regulariser of LossFunction.py:40-51: mean over valid points (point_invalid_mask == 0) of
  * || exp(features[:, 4:7]) ||_2.  value_and_count: device float[2] = {mean, number of valid points}. */

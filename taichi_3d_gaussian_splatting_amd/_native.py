@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSRAST_LIB selects another build of the same library (e.g. the counter-instrumented `make stats` one); no other fallback
 LIB_PATH = os.environ.get("GSRAST_LIB") or os.path.join(_HERE, "lib", "libgsrast.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _I64, _I32, _F32, _VP = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -46,6 +46,15 @@ class GsFrameInfo(C.Structure):
 
 STAGE_PROJECT, STAGE_RASTER = 1, 2
 RECORD_FLOATS, SPLAT_SUM_FLOATS = 16, 12
+
+
+class GsLossImage(C.Structure):
+    """a (3,H,W) f32 image by base pointer and (channel, row, column) strides in floats"""
+    _fields_ = [("data", _VP), ("stride_channel", _I64), ("stride_row", _I64), ("stride_column", _I64)]
+
+    @classmethod
+    def of(cls, t):
+        return cls(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
 
 
 class GsControllerAccumulators(C.Structure):
@@ -89,7 +98,7 @@ EXPORTS = {
 SYMBOLS = ["gs_abi_version", "gs_last_error", "gs_create", "gs_destroy", "gs_forward", "gs_frame_get_info",
            "gs_frame_export_count", "gs_frame_export", "gs_backward", "gs_frame_release", "gs_frame_heavy_tiles",
            "gs_ctx_device_bytes", "gs_ctx_counter_wait_ns", "gs_kernel_names", "gs_profile_enable", "gs_profile_read",
-           "gs_loss_l1_ssim", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
+           "gs_loss_l1_ssim", "gs_loss_maps_floats", "gs_loss_l1_ssim_forward", "gs_loss_l1_ssim_backward", "gs_adam_step", "gs_scale_regulariser", "gs_scale_regulariser_grad",
            "gs_project_shard", "gs_project_shard_begin", "gs_forward_projected", "gs_backward_projected", "gs_backward_shard"]
 
 _lib = None
@@ -162,6 +171,11 @@ def lib():
     L.gs_ctx_device_bytes.argtypes = [_VP]
     L.gs_profile_enable.argtypes = [_VP, C.c_uint64]
     L.gs_loss_l1_ssim.argtypes = [_VP, _VP, _VP, _I32, _I32, _F32, _VP, _VP, _VP]
+    L.gs_loss_maps_floats.argtypes = [_I32, _I32]
+    L.gs_loss_maps_floats.restype = _I64
+    L.gs_loss_l1_ssim_forward.argtypes = [_VP, C.POINTER(GsLossImage), C.POINTER(GsLossImage), _I32, _I32, _I32, _F32, _VP, _VP, _VP]
+    L.gs_loss_l1_ssim_backward.argtypes = [_VP, C.POINTER(GsLossImage), C.POINTER(GsLossImage), _I32, _I32, _I32, _F32, _VP, _VP,
+                                           C.POINTER(GsLossImage), _VP]
     L.gs_scale_regulariser.argtypes = [_VP, _VP, _VP, _I64, _VP, _VP]
     L.gs_scale_regulariser_grad.argtypes = [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]
     L.gs_adam_step.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _I64, _VP]

@@ -1016,6 +1016,52 @@ extern "C" int gs_backward_shard(gs_ctx* c, gs_frame* h, const gs_scene* sc, con
     return GS_OK;
 }
 
+static GsLossImage loss_image(const gs_loss_image* im, int clamp)
+{
+    GsLossImage r; r.p = im->data; r.sc = im->stride_channel; r.sy = im->stride_row; r.sx = im->stride_column; r.clamp = clamp;
+    return r;
+}
+static int loss_check(const char* who, const gs_loss_image* a, const gs_loss_image* b, int32_t H, int32_t W)
+{
+    if (!a || !b || !a->data || !b->data) return fail(GS_ERR_INVALID_ARGUMENT, (std::string(who) + ": NULL image"));
+    if (H < 11 || W < 11) return fail(GS_ERR_INVALID_ARGUMENT, (std::string(who) + ": image smaller than the 11x11 SSIM window"));
+    return GS_OK;
+}
+
+extern "C" int64_t gs_loss_maps_floats(int32_t H, int32_t W) { return (H < 1 || W < 1) ? 0 : (int64_t)gs_loss_maps_size((int)H, (int)W); }
+
+extern "C" int gs_loss_l1_ssim_forward(gs_ctx* c, const gs_loss_image* pred, const gs_loss_image* gt, int32_t H, int32_t W, int32_t clamp_pred,
+                                       float lambda_value, float* maps, float* loss_terms, gs_stream stream_)
+{
+    if (!c || !maps || !loss_terms) return fail(GS_ERR_INVALID_ARGUMENT, "gs_loss_l1_ssim_forward: NULL argument");
+    if (int rc = loss_check("gs_loss_l1_ssim_forward", pred, gt, H, W)) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = c->loss_ws.ensure(gs_loss_partials_floats(H, W) * sizeof(float), &c->device_bytes);
+    if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_loss_l1_ssim_forward: workspace");
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
+    gs_launch_loss_forward(loss_image(pred, clamp_pred != 0), loss_image(gt, 0), H, W, lambda_value, maps, c->loss_ws.as<float>(), loss_terms,
+                           reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_loss_l1_ssim_backward(gs_ctx* c, const gs_loss_image* pred, const gs_loss_image* gt, int32_t H, int32_t W, int32_t clamp_pred,
+                                        float lambda_value, const float* maps, const float* upstream, const gs_loss_image* grad_pred,
+                                        gs_stream stream_)
+{
+    if (!c || !maps || !grad_pred || !grad_pred->data) return fail(GS_ERR_INVALID_ARGUMENT, "gs_loss_l1_ssim_backward: NULL argument");
+    if (int rc = loss_check("gs_loss_l1_ssim_backward", pred, gt, H, W)) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
+    gs_launch_loss_backward(loss_image(pred, clamp_pred != 0), loss_image(gt, 0), H, W, lambda_value, maps, upstream, loss_image(grad_pred, 0),
+                            reinterpret_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return GS_OK;
+}
+
+// the one-call form: contiguous (3,H,W) images, the maps in the context's own workspace, upstream = 1
 extern "C" int gs_loss_l1_ssim(gs_ctx* c, const float* pred, const float* gt, int32_t H, int32_t W, float lambda_value,
                                float* loss_terms, float* grad_pred, gs_stream stream_)
 {
@@ -1023,10 +1069,18 @@ extern "C" int gs_loss_l1_ssim(gs_ctx* c, const float* pred, const float* gt, in
     if (H < 11 || W < 11) return fail(GS_ERR_INVALID_ARGUMENT, "gs_loss_l1_ssim: image smaller than the 11x11 SSIM window");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    hipError_t e = c->loss_ws.ensure(gs_loss_workspace_floats(H, W) * sizeof(float), &c->device_bytes);
+    const size_t maps_floats = gs_loss_maps_size(H, W);
+    hipError_t e = c->loss_ws.ensure((maps_floats + gs_loss_partials_floats(H, W)) * sizeof(float), &c->device_bytes);
     if (e != hipSuccess) return fail(GS_ERR_OUT_OF_MEMORY, "gs_loss_l1_ssim: workspace");
-    HIP_TRY(enter_stream(c, reinterpret_cast<hipStream_t>(stream_)));
-    gs_launch_loss(pred, gt, H, W, lambda_value, c->loss_ws.as<float>(), loss_terms, grad_pred, reinterpret_cast<hipStream_t>(stream_));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(enter_stream(c, s));
+    GsLossImage X{ pred, (long long)H * W, (long long)W, 1, 0 }, Y{ gt, (long long)H * W, (long long)W, 1, 0 };
+    float* maps = c->loss_ws.as<float>();
+    gs_launch_loss_forward(X, Y, H, W, lambda_value, maps, maps + maps_floats, loss_terms, s);
+    if (grad_pred) {
+        GsLossImage G{ grad_pred, (long long)H * W, (long long)W, 1, 0 };
+        gs_launch_loss_backward(X, Y, H, W, lambda_value, maps, nullptr, G, s);
+    }
     HIP_TRY(hipGetLastError());
     return GS_OK;
 }

@@ -326,8 +326,15 @@ struct GsExportArgs { int what; int64_t N; int M; uint32_t K; int T; int depth_b
     const void* keys_sorted; const int32_t* vals_sorted; const int32_t *tile_start, *tile_end; const int8_t* mask; void* dst; };
 void gs_launch_export(const GsExportArgs& a, hipStream_t s);
 
-size_t gs_loss_workspace_floats(int H, int W);
-void gs_launch_loss(const float* X, const float* Y, int H, int W, float lambda, float* workspace, float* terms, float* grad, hipStream_t s);
+// a (3,H,W) f32 image as the loss kernels see it: element (c, y, x) at p[c * sc + y * sy + x * sx] (strides in floats), optionally
+// passed through torch.clamp(., 0, 1) on the fly
+struct GsLossImage { const float* p; long long sc, sy, sx; int clamp; };
+size_t gs_loss_maps_size(int H, int W);          // the three padded derivative maps the forward leaves for the backward
+size_t gs_loss_partials_floats(int H, int W);      // per-block partial sums of the forward
+void gs_launch_loss_forward(const GsLossImage& X, const GsLossImage& Y, int H, int W, float lambda, float* maps, float* partials, float* terms,
+                            hipStream_t s);
+void gs_launch_loss_backward(const GsLossImage& X, const GsLossImage& Y, int H, int W, float lambda, const float* maps, const float* upstream,
+                             const GsLossImage& G, hipStream_t s);
 void gs_launch_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int64_t step, hipStream_t s);
 void gs_launch_reg_value(const float* feat, const int8_t* invalid, int64_t N, float* workspace, float* out, hipStream_t s);

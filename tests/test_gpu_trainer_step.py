@@ -49,6 +49,70 @@ def test_fused_l1_ssim_matches_restatement(H, W):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (45, 70)])
+def test_permuted_rasteriser_layout_and_fused_clamp_equal_the_trainer_lines(H, W):
+    """GaussianPointTrainer.py:173-176: image = clamp(image, 0, 1).permute(2, 0, 1) before the loss.  The fused path reads the
+    (H,W,3) image in place and clamps on the fly: same value, same gradient (zero where the raw value is outside [0, 1]), and
+    the gradient comes back in (H,W,3) memory order.  Also an upstream factor and a second backward through the same node."""
+    from taichi_3d_gaussian_splatting_amd.LossFunction import LossFunction
+    torch.manual_seed(W)
+    gt = torch.rand(3, H, W, device=DEV)
+    raw = (gt.permute(1, 2, 0) + 0.4 * torch.randn(H, W, 3, device=DEV)).contiguous()       # a good part outside [0, 1]
+    raw[0, 0, 0], raw[1, 1, 1] = 0.0, 1.0                                                   # the closed ends pass the gradient
+    lf = LossFunction(LossFunction.LossFunctionConfig(lambda_value=0.2, enable_regularization=False))
+    a = raw.clone().requires_grad_(True)
+    La = 3.0 * lf(torch.clamp(a, 0, 1).permute(2, 0, 1), gt)[0]
+    La.backward()
+    b = raw.clone().requires_grad_(True)
+    Lb, L1b, LDb = lf(b.permute(2, 0, 1), gt, clamp_predicted=True)
+    (3.0 * Lb).backward(retain_graph=True)
+    assert torch.equal(3.0 * Lb, La)
+    assert b.grad.is_contiguous() and torch.equal(b.grad, a.grad)
+    outside = (raw < 0) | (raw > 1)
+    assert outside.float().mean() > 0.2 and not b.grad[outside].any() and b.grad[0, 0, 0] != 0 and b.grad[1, 1, 1] != 0
+    first = b.grad.clone()
+    (3.0 * Lb).backward()
+    assert torch.equal(b.grad, 2 * first)
+    # float64 restatement of the same lines
+    p64 = raw.double().requires_grad_(True)
+    x64 = torch.clamp(p64, 0, 1).permute(2, 0, 1)
+    ref = 0.8 * (x64 - gt.double()).abs().mean() + 0.2 * (1 - ssim_ref(x64[None], gt.double()[None]))
+    ref.backward()
+    assert abs(Lb.item() - ref.item()) < 2e-6
+    assert (first / 3.0 - p64.grad.float()).abs().max().item() / p64.grad.abs().max().item() < 1e-4
+
+
+def test_batched_images_keep_their_own_maps_and_the_one_call_entry_still_answers():
+    """B > 1 (LossFunction.py:21-33): two forwards before the backwards -- each node owns its derivative maps.  And the C ABI's
+    one-call form gs_loss_l1_ssim (contiguous images, upstream 1) gives the same numbers as the two-call form."""
+    import ctypes as C
+    from taichi_3d_gaussian_splatting_amd import _native
+    from taichi_3d_gaussian_splatting_amd.LossFunction import LossFunction
+    torch.manual_seed(5)
+    H, W = 40, 52
+    gt = torch.rand(2, 3, H, W, device=DEV)
+    pred = (gt + 0.1 * torch.randn_like(gt)).clamp(0, 1)
+    lf = LossFunction(LossFunction.LossFunctionConfig(lambda_value=0.2, enable_regularization=False))
+    pb = pred.clone().requires_grad_(True)
+    Lb = lf(pb, gt)[0]
+    Lb.backward()
+    singles, grads = [], []
+    for i in range(2):
+        pi = pred[i].clone().requires_grad_(True)
+        Li = lf(pi, gt[i])[0]
+        Li.backward()
+        singles.append(Li); grads.append(pi.grad)
+    assert torch.allclose(Lb, (singles[0] + singles[1]) / 2, rtol=1e-6)
+    assert torch.allclose(pb.grad, torch.stack(grads) / 2, rtol=1e-5, atol=1e-12)
+    terms = torch.empty(3, device=DEV)
+    g = torch.empty(3, H, W, device=DEV)
+    x, y = pred[1].contiguous(), gt[1].contiguous()
+    _native.check(_native.lib().gs_loss_l1_ssim(_native.shared_ctx(0), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), H, W, 0.2,
+                                                C.c_void_p(terms.data_ptr()), C.c_void_p(g.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gs_loss_l1_ssim")
+    assert torch.equal(terms[0], singles[1].detach()) and torch.equal(g, grads[1])
+
+
 def test_regulariser_and_reference_call_shapes():
     """(1,3,H,W) inputs and the scale regulariser of LossFunction.py:40-51."""
     from taichi_3d_gaussian_splatting_amd.LossFunction import LossFunction

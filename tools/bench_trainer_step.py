@@ -67,7 +67,7 @@ def main():
     fa, fp = FusedAdam([feat_a], lr=1e-3), FusedAdam([pc_a], lr=1e-5)
     ta, tp = torch.optim.Adam([feat_a], lr=1e-3), torch.optim.Adam([pc_a], lr=1e-5)
 
-    def make_iteration(fused):
+    def make_iteration(fused, in_place=False):
         pc = torch.tensor(s.point_cloud, device=DEV, requires_grad=True)
         feat = torch.tensor(s.point_cloud_features, device=DEV, requires_grad=True)
         mask, obj = torch.tensor(s.point_invalid_mask, device=DEV), torch.tensor(s.point_object_id, device=DEV)
@@ -86,7 +86,12 @@ def main():
         def it():
             of.zero_grad(); op.zero_grad()
             img, _, _ = rast(inp)
-            img = torch.clamp(img, 0, 1).permute(2, 0, 1)
+            if in_place:        # the (H,W,3) image read where it lies, clamped inside the loss kernels
+                L = loss_fn(img.permute(2, 0, 1), gt, point_invalid_mask=mask, pointcloud_features=feat, clamp_predicted=True)[0]
+                L.backward()
+                of.step(); op.step()
+                return
+            img = torch.clamp(img, 0, 1).permute(2, 0, 1)               # GaussianPointTrainer.py:173-176 as written
             if fused:
                 L = loss_fn(img, gt, point_invalid_mask=mask, pointcloud_features=feat)[0]
             else:
@@ -95,12 +100,28 @@ def main():
             of.step(); op.step()
         return it
 
+    for flag, hwc in (("--only-loss-chw", False), ("--only-loss-hwc", True)):      # for rocprofv3: the loss kernels alone, one layout
+        if flag in sys.argv:
+            raw = torch.rand(H, W, 3, device=DEV) * 1.4 - 0.2
+
+            def loss_only():
+                if hwc:
+                    p = raw.detach().requires_grad_(True)
+                    lf(p.permute(2, 0, 1), gt, clamp_predicted=True)[0].backward()
+                else:
+                    loss_fused()
+            print(json.dumps({flag: round(timeit(loss_only, n=100, warm=20), 4)}))
+            return
+    if "--only-fused-iteration" in sys.argv:          # for rocprofv3 --kernel-trace --stats: nothing but the fused iteration's launches
+        print(json.dumps({"training_iteration_ms": {"fused_loss_and_adam_image_in_place": round(timeit(make_iteration(True, True), n=100, warm=20), 4)}}))
+        return
     out = {
         "component": "trainer step around the rasteriser (SURVEY 8f-1), config 3, 1x MI355X",
         "loss_fwd_bwd_ms": {"fused_gs_loss_l1_ssim": round(timeit(loss_fused), 4), "torch_conv2d_autograd": round(timeit(loss_torch), 4)},
         "adam_two_tensors_ms": {"fused_gs_adam_step": round(timeit(lambda: (fa.step(), fp.step())), 4),
                                 "torch_optim_adam": round(timeit(lambda: (ta.step(), tp.step())), 4)},
-        "training_iteration_ms": {"fused_loss_and_adam": round(timeit(make_iteration(True), n=100, warm=20), 4),
+        "training_iteration_ms": {"fused_loss_and_adam_image_in_place": round(timeit(make_iteration(True, True), n=100, warm=20), 4),
+                                  "fused_loss_and_adam": round(timeit(make_iteration(True), n=100, warm=20), 4),
                                   "torch_loss_and_adam": round(timeit(make_iteration(False), n=100, warm=20), 4)},
     }
     out["training_iterations_per_s"] = {k: round(1e3 / v, 1) for k, v in out["training_iteration_ms"].items()}
