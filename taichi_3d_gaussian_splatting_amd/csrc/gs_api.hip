@@ -74,6 +74,7 @@ struct Frame {
     bool live = false;
     int cut_cap = 0;                    // list-cut records the forward of this frame could claim (0: it wrote none)
     int bwd_reference_order = 0;        // gs_config.bwd_reference_order of the forward that made the frame (gs_backward_projected has no config)
+    bool max_tiles_known = false;       // k_project of this frame left the largest tile count of one point in the tile arrays (frames from records: no)
     uint32_t generation = 0;
     // gs_project_shard_begin: the hand-over of M (and the object-id check) has not been read yet; slot of the pinned counters
     // the frame's publish kernel writes, its ticket and the stream to fall back on
@@ -433,6 +434,7 @@ static int run_project_stage(gs_ctx* c, Frame* f, const gs_scene* sc, const gs_c
     pa.host_mirror = c->host_counters_dev + slot; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_project(pa, s, wait != WAIT_LATER);      // WAIT_LATER: the caller decides who publishes the counters (run_forward_tail)
+    f->max_tiles_known = true;
     HIP_TRY_F(hipGetLastError());
     *pa_out = pa;
     *M_out = 0; *K_out = 0u; *max_code_out = 0;
@@ -553,6 +555,7 @@ static int run_forward_tail(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
             } else {
                 // the per-pixel half ran on sizes that did not hold: its results are void (not out of bounds).  Again, exactly.
                 HIP_TRY_F(hipMemsetAsync(pa.tile_arrays, 0, sizeof(int32_t) * (size_t)pa.tile_ints, s));
+                f->max_tiles_known = false;                 // (k_project's word went with them: the backward's row sum then looks for giant points itself)
                 if ((rc = run_raster_stage(c, f, pa, n_rows, M, K, bits, H, W, tiles_x, T, cfg, out, s, false)) != GS_OK) return rc;
                 f->info.sizing = GS_SIZING_REDONE;
             }
@@ -724,6 +727,7 @@ extern "C" int gs_forward_projected(gs_ctx* c, const float* records, int64_t m, 
     pa.host_mirror = c->host_counters_dev; pa.ticket = ++c->ticket;
     if (c->ticket == 0x7fffffff) c->ticket = 0;
     gs_launch_boxes_from_records(pa, (int)m, s, false);       // the counters are published from run_forward_tail
+    f->max_tiles_known = false;
     HIP_TRY_F(hipGetLastError());
     uint32_t K = 0; int M_seen = 0;
     if ((rc = run_forward_tail(c, f, pa, m, (int)m, pa.ticket, H, W, tiles_x, T, cfg, out, s, &M_seen, &K)) != GS_OK) return rc;
@@ -889,6 +893,7 @@ static int prepare_backward_blend(gs_ctx* c, const Frame* f, const float* grad_i
     a.gen = c->visit_gen;
     a.touched = c->visited.as<uint8_t>() + flag_bytes;
     a.zero_row = c->zero_row.as<float4>();
+    a.max_tiles_hint = f->max_tiles_known ? B.tile_start.as<int32_t>() + GS_TILE_INTS(f->info.n_tiles) - GS_TILE_SPARE_MAX_TILES : nullptr;
     a.sums = sums_out;
     a.mag_image = mag_image;
     *a_out = a;

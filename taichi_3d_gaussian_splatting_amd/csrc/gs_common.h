@@ -50,6 +50,8 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #define GS_HEAVY_CAP 1024            // most tiles a backward treats as heavy
 // tile arrays of a frame, cleared by its first kernel: tile_start | tile_end | tile_work | tile_cut (first cut record + 1, 0 = none) | cut_alloc
 #define GS_TILE_INTS(T) (4 * (size_t)(T) + 4)
+// the four trailing ints: cut_alloc (k_blend_fwd), then the largest tile count of one point of the frame (k_project -> k_sum_rows), two spare
+#define GS_TILE_SPARE_MAX_TILES 3          // index from the END of the tile arrays
 // tile_order buffer: order (T) | n_heavy | n_items | pad pad | item_base (GS_HEAVY_CAP + 1)
 #define GS_ORDER_INTS(T) ((size_t)(T) + 4 + GS_HEAVY_CAP + 4)
 
@@ -309,6 +311,7 @@ struct GsBackwardArgs {
     uint8_t gen;                    // this backward's tag (1..255): flags are never cleared per backward, a stale one just does not match
     uint8_t* touched;               // (M) == gen where some pixel took a contribution from the point
     const float4* zero_row;         // that row
+    const int32_t* max_tiles_hint;  // device: the frame's largest tile count of one point (k_project), or NULL when nobody computed it
     float4* sums;                   // (M,3) per-point sums of the visited rows (count as int32 bits in [10])
     const float* point_cloud; const float* features; const int32_t* object_id; const float* Kmat; const GsPose* pose;
     int sh_band; float f_color, f_high, f_s, f_q, f_alpha;

@@ -582,6 +582,31 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
 // row, and two quad DPP steps fold the four partial sums.  A point with more rows is summed by its whole wave
 // (lanes stride over the rows, then a DPP reduction), so one huge splat cannot become the critical path.
 #define SUM_ROWS_SMALL 32
+#define SUM_ROWS_GIANT 1024
+// rows first, first + STRIDE, ... of one point: four per thread in flight (flags, then the rows; an unvisited row reads the shared zero
+// row), added in index order
+template <int STRIDE>
+__device__ __forceinline__ void gs_sum_rows_strided(const float4* __restrict__ rows, const uint8_t* __restrict__ vis, const uint8_t gen,
+                                                    const float4* __restrict__ zero_row, const int first, const int cnt, float (&w)[11], int& wpix)
+{
+    for (int i0 = first; i0 < cnt; i0 += 4 * STRIDE) {
+        const float4* r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + STRIDE * k;
+            const bool on = i < cnt && vis[i] == gen;
+            r[k] = on ? rows + 3 * i : zero_row;
+        }
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = r[k][0]; b[k] = r[k][1]; c[k] = r[k][2]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[0] += a[k].x; w[1] += a[k].y; w[2] += a[k].z; w[3] += a[k].w; w[4] += b[k].x; w[5] += b[k].y; w[6] += b[k].z; w[7] += b[k].w;
+            w[8] += c[k].x; w[9] += c[k].y; wpix += __float_as_int(c[k].z);
+        }
+    }
+}
 struct GsMagFold { unsigned first_block; const int32_t* n_heavy; const int32_t* tile_order; const int32_t* tile_cut; const float2* cut_mag;
                    float* mag_image; int W, H, tiles_x; };
 // fold blocks of k_sum_rows (behind the summing ones)
@@ -607,7 +632,8 @@ __device__ __forceinline__ void gs_fold_mag(const GsMagFold& fold)
 
 __global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_t* __restrict__ offsets, const int32_t* __restrict__ ntiles,
                                                   const float* __restrict__ partial, const uint8_t* __restrict__ visited, const uint8_t* __restrict__ touched,
-                                                  const uint8_t gen, const float4* __restrict__ zero_row, float4* __restrict__ sums, const GsMagFold fold)
+                                                  const uint8_t gen, const float4* __restrict__ zero_row, float4* __restrict__ sums, const GsMagFold fold,
+                                                  const int32_t* __restrict__ max_tiles_hint)
 {
     if (blockIdx.x >= fold.first_block) { gs_fold_mag(fold); return; }
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -619,6 +645,16 @@ __global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_
     const bool live = valid && touched[m] == gen;
     const uint32_t off = live ? offsets[m] * (uint32_t)G : 0u;       // G rows per (point, tile) pair
     const int cnt = live ? ntiles[m] * G : 0;
+    // the block's 64 points seen by every wave: which of them are GIANT (summed by the whole block at the end) -- looked for only in a
+    // frame whose largest point can be one (k_project left its tile count; the two extra loads cost 2 us of the launch at the headline config)
+    // A hint that says "none" only moves such a point back to its wave: giant_rows is the one threshold both passes use.
+    unsigned long long giants = 0ull;
+    int giant_rows = 0x7fffffff;
+    if (!max_tiles_hint || max_tiles_hint[0] * G > SUM_ROWS_GIANT) {              // (uniform: a scalar load)
+        giant_rows = SUM_ROWS_GIANT;
+        const int bl = (int)blockIdx.x * 64 + lane;
+        giants = gs_ballot(bl < M && touched[bl] == gen && ntiles[bl] * G > SUM_ROWS_GIANT);
+    }
     float v[11];
     int npix = 0;                                                     // column 10 is an integer count: summed as one
 #pragma unroll
@@ -657,8 +693,10 @@ __global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_
         sums[3 * (size_t)m + 1] = make_float4(v[4], v[5], v[6], v[7]);
         sums[3 * (size_t)m + 2] = make_float4(v[8], v[9], __int_as_float(npix), 0.0f);
     }
-    // wave-cooperative pass over the large points of this wave (one vote per quad leader)
-    unsigned long long big = gs_ballot(valid && q == 0 && cnt > SUM_ROWS_SMALL);
+    // wave-cooperative pass over the large points of this wave (one vote per quad leader); the GIANT ones (a background splat over
+    // the whole image: thousands of rows, 350 KB) are left to the whole block below
+    const bool leader = valid && q == 0;
+    unsigned long long big = gs_ballot(leader && cnt > SUM_ROWS_SMALL && cnt <= giant_rows);
     while (big) {
         const int j = __builtin_ctzll(big);
         big &= big - 1ull;
@@ -671,12 +709,16 @@ __global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_
         int wpix = 0;
 #pragma unroll
         for (int k = 0; k < 11; ++k) w[k] = 0.0f;
-        for (int i = lane; i < bcnt; i += 64) {
-            if (vis[i] == gen) {
-                const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
-                w[0] += a.x; w[1] += a.y; w[2] += a.z; w[3] += a.w; w[4] += b.x; w[5] += b.y; w[6] += b.z; w[7] += b.w;
-                w[8] += c.x; w[9] += c.y; wpix += __float_as_int(c.z);
+        if (bcnt <= 256) {
+            for (int i = lane; i < bcnt; i += 64) {
+                if (vis[i] == gen) {
+                    const float4 a = rows[3 * i], b = rows[3 * i + 1], c = rows[3 * i + 2];
+                    w[0] += a.x; w[1] += a.y; w[2] += a.z; w[3] += a.w; w[4] += b.x; w[5] += b.y; w[6] += b.z; w[7] += b.w;
+                    w[8] += c.x; w[9] += c.y; wpix += __float_as_int(c.z);
+                }
             }
+        } else {
+            gs_sum_rows_strided<64>(rows, vis, gen, zero_row, lane, bcnt, w, wpix);
         }
         gs_wave_sum11_row3(w);
         wpix = gs_wave_sum_i(wpix);
@@ -684,6 +726,45 @@ __global__ __launch_bounds__(256, 7) void k_sum_rows(int M, int G, const uint32_
             sums[3 * (size_t)bm] = make_float4(w[0], w[1], w[2], w[3]);
             sums[3 * (size_t)bm + 1] = make_float4(w[4], w[5], w[6], w[7]);
             sums[3 * (size_t)bm + 2] = make_float4(w[8], w[9], __int_as_float(wpix), 0.0f);
+        }
+    }
+    // block-cooperative pass over the giant points of this block: its 256 threads stride over the rows, four per thread in flight; the
+    // four waves' sums are added in wave order.  Which points are giant is a function of their tile counts alone: fixed order, fixed bits.
+    // Every wave looks at all 64 points of the block itself (one more coalesced load), so a block without giants -- nearly all of
+    // them -- leaves without a barrier (waiting for the slowest wave there cost 3 us of the launch at the headline config).
+    __shared__ float sPart[4][12];
+    const int wave = threadIdx.x >> 6;
+    unsigned long long gm = giants;
+    {
+        while (gm) {
+            const int j = __builtin_ctzll(gm);
+            gm &= gm - 1ull;
+            const int bm = (int)blockIdx.x * 64 + j;
+            const uint32_t boff = offsets[bm] * (uint32_t)G;
+            const int bcnt = ntiles[bm] * G;
+            float w[11];
+            int wpix = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) w[k] = 0.0f;
+            gs_sum_rows_strided<256>(reinterpret_cast<const float4*>(partial + (size_t)boff * PW), visited + boff, gen, zero_row, (int)threadIdx.x, bcnt, w, wpix);
+            gs_wave_sum11_row3(w);
+            wpix = gs_wave_sum_i(wpix);
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) sPart[wave][k] = w[k];
+                sPart[wave][10] = __int_as_float(wpix);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float r[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) r[k] = ((sPart[0][k] + sPart[1][k]) + sPart[2][k]) + sPart[3][k];
+                const int np = (__float_as_int(sPart[0][10]) + __float_as_int(sPart[1][10])) + (__float_as_int(sPart[2][10]) + __float_as_int(sPart[3][10]));
+                sums[3 * (size_t)bm] = make_float4(r[0], r[1], r[2], r[3]);
+                sums[3 * (size_t)bm + 1] = make_float4(r[4], r[5], r[6], r[7]);
+                sums[3 * (size_t)bm + 2] = make_float4(r[8], r[9], __int_as_float(np), 0.0f);
+            }
+            __syncthreads();
         }
     }
 }
@@ -982,7 +1063,7 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         fold.mag_image = a.cuts ? a.mag_image : nullptr; fold.W = a.W; fold.H = a.H; fold.tiles_x = a.tiles_x;
         const unsigned fold_blocks = fold.mag_image ? (unsigned)gs_heavy_cap(a.T) : 0u;
         GS_TIMED(a.prof, KID_SUM_ROWS, s, k_sum_rows<<<fold.first_block + fold_blocks, 256, 0, s>>>(a.M, a.G, a.offsets, a.ntiles, a.partial, a.visited, a.touched,
-                                                                                  a.gen, a.zero_row, a.sums, fold));
+                                                                                  a.gen, a.zero_row, a.sums, fold, a.max_tiles_hint));
     }
     else if (a.M > 0)
         (void)hipMemsetAsync(a.sums, 0, sizeof(float) * PW * (size_t)a.M, s);          // no pairs at all: every sum is zero

@@ -17,12 +17,14 @@
 #endif
 #define SORT_TILE (256 * SORT_ROUNDS)          // keys per tile: 256 threads x SORT_ROUNDS
 
-// One lane per PAIR, not per point: a wave scans its 64 points' tile counts, keeps {first pair, tile box, depth code} of
-// every point in a small LDS table, and then walks the wave's pairs e = 0, 1, 2 ... 64 at a time -- lane l finds the
-// point that owns pair e (binary search over the 64 scanned counts), derives the tile from the pair's position in that
-// point's box (RAST:163-168: tile_u outer, tile_v inner) and stores key and value at slot wave_base + e.  The slots of a
-// wave are consecutive, so every store instruction writes 256 (or 512) consecutive bytes whatever the splat sizes are;
-// a splat covering thousands of tiles is simply many iterations in which all lanes find the same owner.
+// One lane per PAIR, not per point: a block scans its 256 points' tile counts, keeps {first pair, tile box, depth code} of
+// every point in a small LDS table, and then walks the BLOCK's pairs e = 0, 1, 2 ... 256 at a time -- a thread finds the
+// point that owns pair e (binary search over the 256 scanned counts), derives the tile from the pair's position in that
+// point's box (RAST:163-168: tile_u outer, tile_v inner) and stores key and value at slot block_base + e.  The slots of a
+// block are consecutive, so every store instruction writes 256 (or 512) consecutive bytes per wave whatever the splat sizes
+// are; a splat covering thousands of tiles is simply many iterations in which all threads find the same owner -- shared by the
+// block's four waves (walked by its own wave alone, one background splat over the whole image was 120 iterations of one wave
+// against 8 for the others: k_keygen 51 us on the clustered workload with fewer pairs than the uniform one's 22 us).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ depth_codes, const ushort4* __restrict__ boxes,
                                                 const int32_t* __restrict__ ntiles,
@@ -36,9 +38,9 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
 {
     __shared__ uint32_t ws[4];
     __shared__ uint32_t wpre[4];
-    __shared__ uint32_t sExcl[4][64];
-    __shared__ ushort4 sBox[4][64];
-    __shared__ KeyT sCode[4][64];
+    __shared__ uint32_t sExcl[256 + 1];
+    __shared__ ushort4 sBox[256];
+    __shared__ KeyT sCode[256];
     // same blocks as the kernel that produced ntiles / tile_block_offsets: k_project's (256 rows of the point cloud each, in-camera
     // points dense from block_offsets[b]) or, for records that arrived from elsewhere, 256 consecutive records
     const int first = block_offsets ? block_offsets[blockIdx.x] : (int)blockIdx.x * 256;
@@ -51,9 +53,8 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
     if (lane == 63) ws[wave] = incl;
-    sExcl[wave][lane] = incl - n;
-    sBox[wave][lane] = valid ? boxes[idx] : make_ushort4(0, 1, 0, 1);
-    sCode[wave][lane] = valid ? (KeyT)(uint32_t)depth_codes[idx] : (KeyT)0;     // i32(depth * scale), RAST:159-160, from k_project
+    sBox[threadIdx.x] = valid ? boxes[idx] : make_ushort4(0, 1, 0, 1);
+    sCode[threadIdx.x] = valid ? (KeyT)(uint32_t)depth_codes[idx] : (KeyT)0;     // i32(depth * scale), RAST:159-160, from k_project
     // first pair of this block = the tile counts of all blocks before it (RAST:913-922 across blocks): a few thousand L2-resident
     // counters summed by the block itself, instead of a scan launch in between
     uint32_t pre = 0;
@@ -62,22 +63,24 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
     if (lane == 0) wpre[wave] = pre;
     __syncthreads();
     const uint32_t block_base = wpre[0] + wpre[1] + wpre[2] + wpre[3];
+    const uint32_t block_total = ws[0] + ws[1] + ws[2] + ws[3];
     // the last block knows K = its base + its own count: it hands the frame counters to the host when the launch was queued
     // before the host had them (predicted sizing; k_project.hip: gs_publish_counters)
     if (host_mirror && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        gs_publish_counters(counters, block_base + ws[0] + ws[1] + ws[2] + ws[3], host_mirror, ticket);
+        gs_publish_counters(counters, block_base + block_total, host_mirror, ticket);
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += ws[w];
-    const uint32_t wave_base = block_base + woff;                                 // slot of the wave's first pair
-    if (valid) offsets[idx] = wave_base + incl - n;                               // RAST:913-922 (also the backward's row slots)
-    const uint32_t wave_total = ws[wave];
-    const int wave_first_point = first + (int)(threadIdx.x & ~63u);
-    for (uint32_t e = (uint32_t)lane; e < wave_total; e += 64u) {
+    const uint32_t excl = woff + incl - n;                                        // first pair of this point inside the block
+    sExcl[threadIdx.x] = excl;
+    if (threadIdx.x == 0) sExcl[256] = 0xffffffffu;
+    if (valid) offsets[idx] = block_base + excl;                                  // RAST:913-922 (also the backward's row slots)
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < block_total; e += 256u) {
         int j = 0;                                                                // owner: the last point whose first pair is <= e
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) if (sExcl[wave][j + step] <= e) j += step;
-        const uint32_t t = e - sExcl[wave][j];                                    // position in the owner's box
-        const ushort4 bx = sBox[wave][j];
+        for (int step = 128; step > 0; step >>= 1) if (sExcl[j + step] <= e) j += step;
+        const uint32_t t = e - sExcl[j];                                          // position in the owner's box
+        const ushort4 bx = sBox[j];
         const uint32_t dv = (uint32_t)((int)bx.w - (int)bx.z);
         // t / dv: float estimate + one correction step either way (exact below 2^22; a box has at most tiles_x * tiles_y entries)
         uint32_t tq, tr;
@@ -89,10 +92,10 @@ __global__ __launch_bounds__(256) void k_keygen(const int32_t* __restrict__ dept
             tr = (uint32_t)r;
         } else { tq = t / dv; tr = t - tq * dv; }
         const KeyT tile_id = (KeyT)(((uint32_t)bx.x + tq) + ((uint32_t)bx.z + tr) * (uint32_t)tiles_x);   // RAST:163-168
-        const uint32_t slot = wave_base + e;
+        const uint32_t slot = block_base + e;
         if (slot < K_cap) {
-            keys[slot] = (tile_id << depth_bits) | sCode[wave][j];               // RAST:169-170, compact form
-            vals[slot] = wave_first_point + j;
+            keys[slot] = (tile_id << depth_bits) | sCode[j];                     // RAST:169-170, compact form
+            vals[slot] = first + j;
         }
     }
     (void)depth_scale;

@@ -134,10 +134,11 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
                                                  float4* __restrict__ PA, float4* __restrict__ PB, float4* __restrict__ PC,
                                                  float4* __restrict__ PD, ushort4* __restrict__ boxes,
                                                  int32_t* __restrict__ ntiles, uint32_t* __restrict__ tile_block_sums,
-                                                 GsCounters* counters, int32_t* __restrict__ depth_codes)
+                                                 GsCounters* counters, int32_t* __restrict__ depth_codes, int32_t* __restrict__ max_tiles_hint)
 {
     __shared__ int wave_sum[4];
     __shared__ int wave_max[4];
+    __shared__ int wave_maxn[4];
     // the four float4 of a record leave through LDS: a lane-per-record store writes 16 bytes out of every 64 per
     // instruction; staged, each of the wave's four store instructions writes 1 KB of consecutive bytes
     __shared__ float4 sOut[4][4 * 64];
@@ -308,12 +309,17 @@ __global__ __launch_bounds__(256) void k_project(const float* __restrict__ pc, f
 #endif
     int s = gs_wave_sum_i(count);
     int mx = gs_wave_max_i(depth_code);
-    if (lane == 0) { wave_sum[wave] = s; wave_max[wave] = mx; }
+    int mn = gs_wave_max_i(count);
+    if (lane == 0) { wave_sum[wave] = s; wave_max[wave] = mx; wave_maxn[wave] = mn; }
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_block_sums[blockIdx.x] = (uint32_t)(wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]);
         int m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
         if (m > 0) atomicMax(&counters->max_depth_code, m);
+        // the frame's largest tile count of one point (a word of the tile arrays, cleared by k_filter): the backward's row sum looks for
+        // points with thousands of rows only in a frame that has any (k_backward.hip: SUM_ROWS_GIANT)
+        const int mt = max(max(wave_maxn[0], wave_maxn[1]), max(wave_maxn[2], wave_maxn[3]));
+        if (max_tiles_hint && mt > 64) atomicMax(max_tiles_hint, mt);
     }
 }
 
@@ -398,7 +404,8 @@ void gs_launch_project(const GsProjectArgs& a, hipStream_t s, bool publish)
     GS_TIMED(a.prof, KID_PROJECT, s, k_project<<<nb, 256, 0, s>>>(a.point_cloud, a.features, a.object_id, a.Kmat, a.pose, a.mask, a.block_counts, a.N,
                                                               a.ids, a.cam_index, a.block_offsets, a.W, a.H,
                                                               a.depth_scale, a.PA, a.PB, a.PC, a.PD, a.box, a.ntiles,
-                                                              a.tile_block_sums, a.counters, a.depth_codes));
+                                                              a.tile_block_sums, a.counters, a.depth_codes,
+                                                              a.tile_arrays ? a.tile_arrays + a.tile_ints - GS_TILE_SPARE_MAX_TILES : nullptr));
     if (publish) gs_launch_publish(a, nb, s);
 }
 

@@ -86,6 +86,23 @@ def test_large_and_degenerate_splats(P):
     assert (f.pixel_accumulated_alpha > 0.9998).any()          # the T < 1e-4 stop is exercised
 
 
+@pytest.mark.parametrize("n,w,h,rows_per_pair", [(3000, 640, 400, 4), (20000, 1536, 1024, 1)])
+def test_splats_covering_most_of_the_image(P, n, w, h, rows_per_pair):
+    """A few translucent background splats whose 3-sigma box covers (nearly) every tile, among ordinary ones: more than a thousand
+    (point, tile) rows each.  k_keygen walks such a splat's pairs with the whole block, k_sum_rows sums its rows with the whole
+    block (k_backward.hip: SUM_ROWS_GIANT), one more with its wave (> 32 rows), the rest four lanes per point."""
+    s = synth(n, w, h, 0.02, sh_deg=3, seed=21)
+    s.point_cloud_features[:6, 4:7] = np.log(2.5)              # six splats far larger than the image
+    s.point_cloud_features[:6, 7] = -3.0                       # faint: everything behind them still counts
+    s.point_cloud[:6, :2] *= 0.2                               # near the optical axis
+    s.point_cloud_features[6:40, 4:7] = np.log(0.3)            # and some that cover a few hundred tiles
+    s.point_cloud_features[6:40, 7] = -2.0
+    q, t = view_pose()
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=3, hook=True, seed=5)
+    rows = np.asarray(f.num_overlap_tiles).astype(np.int64) * rows_per_pair
+    assert (rows > 1024).sum() >= 3 and ((rows > 32) & (rows <= 1024)).sum() >= 10, (rows.max(), (rows > 1024).sum())
+
+
 @pytest.mark.parametrize("case", ["empty", "all_invalid", "behind", "one_point"])
 def test_edge_cases(P, case):
     s = synth(64, 64, 48 if False else 64, 0.1, seed=3)
