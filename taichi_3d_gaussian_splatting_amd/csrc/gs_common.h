@@ -45,12 +45,19 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 #define GS_NFEAT 56
 // Cuts of long tile lists (k_blend_fwd writes them, the backward blend of a HEAVY tile starts its segments from them): every
 // GS_SEG entries of a list longer than GS_CUT_MIN_LEN the forward stores each pixel's transmittance and accumulated colour.
+// Every list longer than one segment is cut: a dense list of 600 - 1000 entries, left whole, is twice the longest segment and was
+// what the backward of the clustered 976x544 workload waited for (0.224 -> 0.179 ms; 1024 was the threshold while cutting cost
+// an atomic claim and a barrier at the head of the list -- k_blend_fwd.hip).  Segments of 256 entries: no further gain (0.183).
+#ifndef GS_SEG
 #define GS_SEG 512
-#define GS_CUT_MIN_LEN 1024
+#endif
+#ifndef GS_CUT_MIN_LEN
+#define GS_CUT_MIN_LEN 512
+#endif
 #define GS_HEAVY_CAP 1024            // most tiles a backward treats as heavy
 // tile arrays of a frame, cleared by its first kernel: tile_start | tile_end | tile_work | tile_cut (first cut record + 1, 0 = none) | cut_alloc
 #define GS_TILE_INTS(T) (4 * (size_t)(T) + 4)
-// the four trailing ints: cut_alloc (k_blend_fwd), then the largest tile count of one point of the frame (k_project -> k_sum_rows), two spare
+// the four trailing ints: one unused (the cut records' claim counter until their positions became a closed form), then the largest tile count of one point of the frame (k_project -> k_sum_rows), two spare
 #define GS_TILE_SPARE_MAX_TILES 3          // index from the END of the tile arrays
 // tile_order buffer: order (T) | n_heavy | n_items | pad pad | item_base (GS_HEAVY_CAP + 1)
 #define GS_ORDER_INTS(T) ((size_t)(T) + 4 + GS_HEAVY_CAP + 4)

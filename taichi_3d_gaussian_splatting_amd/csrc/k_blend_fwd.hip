@@ -87,21 +87,17 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int32_t* __restrict__ tile_st
     // the cut and the colour of the segment that just ended (16 bytes), once more at the end of the walk -- the backward can
     // then start anywhere in the list (k_backward.hip: heavy tiles are handed out segment by segment), and what it needs there,
     // the colour BEHIND the cut, is a sum of later segments' colours: small terms added to small terms, as in the reference's own
-    // back-to-front accumulation (a difference of front sums would lose exactly the digits a dim pixel lives on).  Records are
-    // claimed with one atomic per long list; when the buffer is full the tile simply has none.
-    __shared__ int sCut;
+    // back-to-front accumulation (a difference of front sums would lose exactly the digits a dim pixel lives on).  A list's
+    // records sit at start / GS_SEG + tile: the lists are disjoint ranges of the sorted pairs, so the next tile's first record
+    // lies at least (length / GS_SEG) + 1 further on -- room for all of this one's, without an atomic claim (and the barrier
+    // behind it) at the head of every long list; K / GS_SEG + T + 1 records hold them all.
     const bool long_list = end - start > GS_CUT_MIN_LEN;                               // (workgroup-uniform)
     int cut_base = -1;
     if (!RGB_ONLY && cut_cap > 0 && long_list) {
-        if (threadIdx.x == 0) {
-            const int n_rec = (end - start - 1) / GS_SEG + 1;
-            int b = atomicAdd(cut_alloc, n_rec);
-            if (b + n_rec > cut_cap) b = -1;
-            sCut = b;
-            tile_cut[tile] = b + 1;
-        }
-        __syncthreads();
-        cut_base = sCut;
+        const int n_rec = (end - start - 1) / GS_SEG + 1;
+        const int b = start / GS_SEG + tile;
+        if (b + n_rec <= cut_cap) cut_base = b;
+        if (threadIdx.x == 0) tile_cut[tile] = cut_base + 1;
     }
     int next_rec = 0;                                                                  // cut records this wave has written
     float tot_r = 0.0f, tot_g = 0.0f, tot_b = 0.0f;                                    // colour of the segments behind the last cut

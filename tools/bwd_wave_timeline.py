@@ -71,3 +71,8 @@ hv = idx < heavy_waves
 if hv.any() and (~hv).any():
     print(f"heavy items: {hv.sum()} waves, duration mean {dur[hv].mean() / 100:.1f} us max {dur[hv].max() / 100:.1f}, last end {en[hv].max() / span:.2f} of the span; "
           f"ordinary: {(~hv).sum()} waves, mean {dur[~hv].mean() / 100:.1f} us max {dur[~hv].max() / 100:.1f}, last end {en[~hv].max() / span:.2f}")
+
+if os.environ.get("GS_TIMELINE_DUMP"):      # raw records for a closer look: wave id, start, end (ticks from the first start), plus the tile lists' lengths
+    lens = (module.last_frame.export("tile_points_end").cpu().numpy().astype(np.int64)
+            - module.last_frame.export("tile_points_start").cpu().numpy().astype(np.int64))
+    np.savez(os.environ["GS_TIMELINE_DUMP"], idx=idx, st=st, en=en, n_heavy=n_heavy, n_items=n_items, G=G, tile_len=lens)
