@@ -149,7 +149,7 @@ extern "C" const char* gs_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* gs_kernel_names(void)
 {
     return "k_filter,k_scan_tiles_publish,k_project,k_keygen,k_sort_hist,"
-           "k_sort_rowscan,k_sort_scatter,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order";
+           "k_sort_rowscan,k_sort_scatter,k_blend_fwd,k_blend_bwd_tile,k_bwd_points,k_sum_rows,k_tile_order,k_blend_bwd_repair";
 }
 
 extern "C" int gs_create(int32_t device, gs_ctx** out)

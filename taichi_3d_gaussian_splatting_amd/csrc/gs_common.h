@@ -60,7 +60,8 @@ extern __device__ unsigned long long gs_stats_wave_times[2 * 65536];   // start,
 // the four trailing ints: one unused (the cut records' claim counter until their positions became a closed form), then the largest tile count of one point of the frame (k_project -> k_sum_rows), two spare
 #define GS_TILE_SPARE_MAX_TILES 3          // index from the END of the tile arrays
 // tile_order buffer: order (T) | n_heavy | n_items | pad pad | item_base (GS_HEAVY_CAP + 1)
-#define GS_ORDER_INTS(T) ((size_t)(T) + 4 + GS_HEAVY_CAP + 4)
+#define GS_ORDER_INTS(T) ((size_t)(T) + 4 + GS_HEAVY_CAP + 4 + GS_HEAVY_CAP)
+#define GS_ORDER_REDO_OFFSET (4 + GS_HEAVY_CAP + 4)      // from n_heavy: one flag per heavy tile, "walk this tile again in one piece" (k_backward.hip)
 
 // Per-object pose record built once per frame (every k_filter block derives it, block 0 stores it).
 struct GsPose {
@@ -233,7 +234,7 @@ __device__ __forceinline__ int gs_wave_max_i(int v)
 // Kernel ids index the comma-separated list returned by gs_kernel_names().
 enum GsKernelId { KID_FILTER = 0, KID_PUBLISH, KID_PROJECT, KID_KEYGEN,
                   KID_SORT_HIST, KID_SORT_ROWSCAN, KID_SORT_SCATTER, KID_BLEND_FWD,
-                  KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_COUNT_ };
+                  KID_BLEND_BWD, KID_BWD_POINTS, KID_SUM_ROWS, KID_TILE_ORDER, KID_BLEND_BWD_REPAIR, KID_COUNT_ };
 struct GsProf;
 int gs_prof_begin(GsProf* p, int kid, hipStream_t s);     // returns a record index or -1
 void gs_prof_end(GsProf* p, int rec, hipStream_t s);

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     __shared__ unsigned long long wtot[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < ORDER_BINS; i += 1024) bins[i] = 0;
+    if (t < HEAVY_CAP) n_heavy_out[GS_ORDER_REDO_OFFSET + t] = 0;          // no heavy tile has asked to be walked again yet
     __syncthreads();
     unsigned long long total = 0ull;
     // ORDER_PER loads in flight per thread (the kernel is one workgroup deep in load latency, not in work)
@@ -188,7 +189,17 @@ struct BwdCoop { unsigned long long* done; int32_t* slot; int32_t* point; int32_
                  // the SEGMENT of the tile's list this workgroup walks (seg of nseg; nseg == 1: the whole list), the forward's cut
                  // records of the tile (256 float4 each; record k: T before entry start + (k + 1) GS_SEG and the colour blended in
                  // segment k; record nseg - 1: the final T and the last segment's colour) and where a segment leaves its |d uv| sums
-                 int seg, nseg; const float4* cut_rec; float2* mag_part; };
+                 int seg, nseg; const float4* cut_rec; float2* mag_part;
+                 // A segment starts from the FORWARD's transmittance at its cut.  The reference decides "does this splat contribute"
+                 // (alpha >= 1/255) once in its forward and again, from another expression, in its backward (UTIL:257-284 against
+                 // UTIL:331-348): for an alpha within an ulp of 1/255 the two can disagree, and the reference's backward chain then
+                 // differs from its forward chain by that splat's factor 1 - 1/255.  A walk that starts from 1 - accumulated_alpha
+                 // and decides for itself reproduces that; a start taken from the forward's T does not (0.39 % on the contributions of
+                 // the segments in front of such a splat: one soak scene in 300 once every list over 512 entries was cut).  So every
+                 // segment compares the T it arrives at, at its front edge, with the forward's record there; a difference of 1e-3
+                 // (rounding stays below 1e-4 over 512 steps, the disagreement is 3.9e-3) sets this flag and k_blend_bwd_repair
+                 // walks the tile again in one piece, over the same rows.
+                 int32_t* redo; };
 
 template <int NQ, bool STRICT, bool COOP>
 __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, const int G_rows, float4 (*sRec)[3], float* sRed, const BwdCoop coop,
@@ -213,6 +224,7 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
     const int seg_hi = (COOP && coop.nseg > 1 && coop.seg < coop.nseg - 1) ? start + (coop.seg + 1) * GS_SEG : end;
     const int lx = lane & 7, ly = lane >> 3;
     QuadState Q[NQ];
+    float t_end[COOP ? NQ : 1];                  // COOP: the pixel's 1 - accumulated_alpha (the segment check at the end)
     int qlast[NQ];
     float rx0[NQ], ry0[NQ];
 #pragma unroll
@@ -224,6 +236,7 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
         const size_t o = inside ? (size_t)pv * (size_t)W + (size_t)pu : 0;
         Q[qi].last = inside ? last_in[o] : start;                    // RAST:558
         Q[qi].T = 1.0f - acc_alpha[o];                               // RAST:559-560
+        if constexpr (COOP) t_end[qi] = Q[qi].T;
         Q[qi].W = 0.0f;
         Q[qi].gr = grad_image[3 * o]; Q[qi].gg = grad_image[3 * o + 1]; Q[qi].gb = grad_image[3 * o + 2];
         Q[qi].tot0 = Q[qi].tot1 = 0.0f;
@@ -490,6 +503,21 @@ __device__ __forceinline__ void gs_bwd_tile_body(const int tile, const int grp, 
             }
         }
     }
+    if constexpr (COOP) {
+        if (coop.redo && coop.nseg > 1 && coop.seg > 0) {
+            const float4* rec = coop.cut_rec + grp * 64 + lane;
+            bool differs = false;
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                if (Q[qi].last > seg_lo) {                                       // the pixel walked (part of) this segment: Q.T is its T before entry seg_lo
+                    const float t_final = rec[(size_t)(coop.nseg - 1) * 256].x;
+                    const float expect = rec[(size_t)(coop.seg - 1) * 256].x * (t_final > 0.0f ? t_end[qi] / t_final : 1.0f);
+                    differs = differs || fabsf(Q[qi].T - expect) > 1.0e-3f * expect;
+                }
+            }
+            if (gs_ballot(differs) != 0ull && lane == 0) *coop.redo = 1;
+        }
+    }
 #ifdef GS_STATS
     {
         const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -549,7 +577,7 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
     BwdCoop coop;
     coop.done = sDone; coop.slot = sSlot; coop.point = sPoint; coop.tile_last = sTileLast;
     coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
-    coop.seg = 0; coop.nseg = 1; coop.cut_rec = nullptr; coop.mag_part = nullptr;
+    coop.seg = 0; coop.nseg = 1; coop.cut_rec = nullptr; coop.mag_part = nullptr; coop.redo = nullptr;
     // (heavy items first: handing them out BEHIND the ordinary tiles, as the short jobs they are, measured slower -- DESIGN.md section 5)
     const int hb = (int)blockIdx.x < n_items ? (int)blockIdx.x : -1;
     const int lb = (int)blockIdx.x - n_items;
@@ -563,6 +591,7 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
         if (coop.nseg > 1) {
             const size_t first = (size_t)(tile_cut[tile] - 1) * 256;
             coop.cut_rec = cuts + first; coop.mag_part = cut_mag + first;
+            coop.redo = const_cast<int32_t*>(n_heavy_ptr) + GS_ORDER_REDO_OFFSET + h;
         }
         gs_bwd_tile_body<1, STRICT, true>(tile, wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
                                           PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
@@ -573,6 +602,36 @@ __global__ __launch_bounds__(256, GS_BWD_MIN_WAVES) void k_blend_bwd_tile(const 
     if (ti >= T) return;
     gs_bwd_tile_body<NQ, STRICT, false>(tile_order[ti], item % G, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
                                         PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
+}
+
+// Heavy tiles whose segments found the forward's transmittance at a cut at odds with their own walk (BwdCoop::redo): the whole
+// list again, in one piece, from 1 - accumulated_alpha, over the same rows, flags and pixels.  One workgroup per heavy tile; all
+// but the flagged ones (normally none) leave at once.  Launched only for frames with cut lists.
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_blend_bwd_repair(const int32_t* __restrict__ tile_order, const int32_t* __restrict__ n_heavy_ptr, int G,
+                                                          const int32_t* __restrict__ tile_start, const int32_t* __restrict__ tile_end,
+                                                          const int32_t* __restrict__ sorted_vals,
+                                                          const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                                          const float4* __restrict__ PC, const ushort4* __restrict__ boxes,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const float* __restrict__ grad_image, const float* __restrict__ acc_alpha,
+                                                          const int32_t* __restrict__ last_in, int W, int H, int tiles_x,
+                                                          float* __restrict__ partial, uint8_t* __restrict__ visited, uint8_t* __restrict__ touched,
+                                                          const uint8_t gen, float* __restrict__ mag_image)
+{
+    const int h = (int)blockIdx.x;
+    if (h >= n_heavy_ptr[0] || n_heavy_ptr[GS_ORDER_REDO_OFFSET + h] == 0) return;
+    __shared__ float4 sRecAll[4][64][3];
+    __shared__ __attribute__((aligned(16))) float sRedAll[4][11 * RED_STRIDE];
+    __shared__ unsigned long long sDone[4];
+    __shared__ int32_t sSlot[64], sPoint[64], sTileLast[4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    BwdCoop coop;
+    coop.done = sDone; coop.slot = sSlot; coop.point = sPoint; coop.tile_last = sTileLast;
+    coop.slab = reinterpret_cast<float (*)[64][12]>(&sRecAll[0][0][0]);
+    coop.seg = 0; coop.nseg = 1; coop.cut_rec = nullptr; coop.mag_part = nullptr; coop.redo = nullptr;
+    gs_bwd_tile_body<1, STRICT, true>(tile_order[h], wave, G, sRecAll[wave], sRedAll[wave], coop, tile_start, tile_end, sorted_vals,
+                                      PA, PB, PC, boxes, offsets, grad_image, acc_alpha, last_in, W, H, tiles_x, partial, visited, touched, gen, mag_image);
 }
 
 // ---------------------------------------------------------------------------------
@@ -619,6 +678,7 @@ __device__ __forceinline__ void gs_fold_mag(const GsMagFold& fold)
         const int32_t* item_base = fold.n_heavy + 4;
         const int nseg = item_base[h + 1] - item_base[h];
         if (nseg <= 1) return;
+        if (fold.n_heavy[GS_ORDER_REDO_OFFSET + h] != 0) return;              // walked again in one piece (k_blend_bwd_repair): its pixels' sums are final
         const int tile = fold.tile_order[h];
         const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const int pu = (tile % fold.tiles_x) * 16 + (q & 1) * 8 + (lane & 7), pv = (tile / fold.tiles_x) * 16 + (q >> 1) * 8 + (lane >> 3);
@@ -1053,6 +1113,14 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true); else GS_BWD_LAUNCH(2, false); }
         else { if (a.strict) GS_BWD_LAUNCH(1, true); else GS_BWD_LAUNCH(1, false); }
 #undef GS_BWD_LAUNCH
+        if (a.cuts) {
+#define GS_BWD_REPAIR(STRICT_)                                                                                                          \
+            GS_TIMED(a.prof, KID_BLEND_BWD_REPAIR, s, k_blend_bwd_repair<STRICT_><<<(unsigned)gs_heavy_cap(a.T), 256, 0, s>>>(a.tile_order, a.n_heavy, a.G, \
+                     a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H,  \
+                     a.tiles_x, a.partial, a.visited, a.touched, a.gen, a.mag_image))
+            if (a.strict) GS_BWD_REPAIR(true); else GS_BWD_REPAIR(false);
+#undef GS_BWD_REPAIR
+        }
     }
     else if (a.mag_image)
         (void)hipMemsetAsync(a.mag_image, 0, sizeof(float) * 2 * (size_t)a.H * (size_t)a.W, s);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     kernels = L.gs_kernel_names().decode().split(",")
     csrc = os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "csrc")
     text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip"))
-    assert len(kernels) == len(set(kernels)) == 12
+    assert len(kernels) == len(set(kernels)) == 13
     for k in kernels:
         assert re.search(r"__global__[^;{]*\b" + k + r"\s*\(", text), f"{k} is listed by gs_kernel_names() but is not a kernel"
 

@@ -772,6 +772,23 @@ def test_heavy_set_and_cuts_do_not_depend_on_claim_order(P):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_contributor_on_the_alpha_threshold_behind_a_cut(P):
+    """Soak scene 800305 (192x288, lists of 700 - 2400 entries, 20 heavy tiles walked in segments): one pixel has a contributor
+    whose alpha sits within an ulp of 1/255 behind a cut.  The reference decides "contributes" once in its forward and again, from
+    another expression, in its backward; they disagree there, so the reference's backward chain differs from its forward chain by
+    that splat's factor.  A segment that starts from the forward's transmittance would carry the forward's decision (0.39 % on that
+    pixel's contributions in front of the cut, five times the per-element bar); the segments notice the disagreement at their
+    front edge and the tile is walked again in one piece (k_backward.hip: BwdCoop::redo, k_blend_bwd_repair)."""
+    c = P.soak_case(800305)
+    s, q, t = c["scene"], c["q"], c["t"]
+    module, inp, f, b, _ = _fwd_bwd(P, s, q, t, band=c["band"], hook=True, cfg_kw=dict(allow_partial_tiles=bool(c["partial"])), seed=3)
+    import os
+    if not any(k in os.environ for k in ("GS_BWD_SPLIT_HEAVY", "GS_BWD_SEGMENTS", "GS_BWD_HEAVY_X2")):
+        fr = module.last_frame
+        assert fr.heavy_tiles() > 0 and fr.heavy_tiles(items=True) > fr.heavy_tiles()
+    assert max(m["bar_use_max"] for m in b["margins"].values()) < 0.6
+
+
 def test_second_backward_through_a_frame_with_cut_lists(P):
     """backward(retain_graph=True) twice on a frame whose heavy tiles are walked in segments: the forward's cut records are read-only
     for the backward and the segments' partial sums are rewritten with the same values, so the second pass adds exactly the same

@@ -29,3 +29,29 @@ print({k: (round(v["bar_use_max"], 2), "%.1e" % P.rel_err(gp if k == "xyz" else 
 mi = module.last_backward_extras["magnitude_grad_viewspace_on_image"].cpu().numpy()
 print("mag image rel err", P.rel_err(mi, b["magnitude_grad_viewspace_on_image"]))
 np.save(os.path.join(ROOT, "gpurun_out", f"dbg_gp_{os.environ.get('GS_BWD_SEGMENTS','1')}.npy"), gp)
+# the worst element against the per-element bar: which point, which tiles hold it and how long their lists are
+mx = m["xyz"]
+err = np.abs(gp - b["grad_pointcloud"])
+summed = b.get("summed_pointcloud")
+if summed is not None:
+    use = err / np.maximum(summed, 1e-30)
+    flat = np.argsort(use.ravel())[::-1][:6]
+    ids = np.asarray(f.point_id_in_camera_list)
+    cam_of = {int(p): i for i, p in enumerate(ids)}
+    box = None
+    for fl in flat:
+        p, comp = divmod(int(fl), 3)
+        print("point", p, "component", comp, "got %.6e ref %.6e err %.2e summed %.3e err/summed %.2e" % (gp[p, comp], b["grad_pointcloud"][p, comp], err[p, comp], summed[p, comp], use[p, comp]),
+              "tiles covered", int(np.asarray(f.num_overlap_tiles)[cam_of[p]]) if p in cam_of else None)
+    # tiles holding the worst point: from the sorted values
+    p = int(flat[0]) // 3
+    m_idx = cam_of.get(p)
+    vals = np.asarray(f.point_offset_with_sort_key)
+    if vals is not None and m_idx is not None:
+        pos = np.nonzero(vals == m_idx)[0]
+        ts, te = np.asarray(f.tile_points_start), np.asarray(f.tile_points_end)
+        for ps in pos[:12]:
+            tl = int(np.nonzero((ts <= ps) & (te > ps))[0][0])
+            print("   in tile", tl, "list", int(ts[tl]), int(te[tl]), "len", int(te[tl] - ts[tl]), "position in list", int(ps - ts[tl]))
+np.save(os.path.join(ROOT, "gpurun_out", f"dbg_mag_{os.environ.get('GS_BWD_SEGMENTS','1')}.npy"), mi)
+np.save(os.path.join(ROOT, "gpurun_out", "dbg_mag_ref.npy"), b["magnitude_grad_viewspace_on_image"])
