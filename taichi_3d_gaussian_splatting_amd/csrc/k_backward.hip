@@ -1113,7 +1113,7 @@ void gs_launch_backward_blend(const GsBackwardArgs& a, hipStream_t s)
         else if (a.G == 2) { if (a.strict) GS_BWD_LAUNCH(2, true); else GS_BWD_LAUNCH(2, false); }
         else { if (a.strict) GS_BWD_LAUNCH(1, true); else GS_BWD_LAUNCH(1, false); }
 #undef GS_BWD_LAUNCH
-        if (a.cuts) {
+        if (a.cuts && gs_heavy_cap(a.T) > 0) {                 // (fewer than eight tiles: no tile can be heavy)
 #define GS_BWD_REPAIR(STRICT_)                                                                                                          \
             GS_TIMED(a.prof, KID_BLEND_BWD_REPAIR, s, k_blend_bwd_repair<STRICT_><<<(unsigned)gs_heavy_cap(a.T), 256, 0, s>>>(a.tile_order, a.n_heavy, a.G, \
                      a.tile_start, a.tile_end, a.vals_sorted, a.PA, a.PB, a.PC, a.box, a.offsets, a.grad_image, a.acc_alpha, a.last, a.W, a.H,  \
