@@ -462,8 +462,9 @@ static int run_raster_stage(gs_ctx* c, Frame* f, const GsProjectArgs& pa, int64_
     const bool want_cuts = seg_env >= 0 ? seg_env == 1 : (int64_t)T * waves_per_tile(T) < 6144;
     int cut_cap = 0;
     if (want_cuts && f->info.kept_for_backward && !cfg->rgb_only && K_bound > 0) {
-        // every long list can have its records: sum over lists of ((L - 1) / GS_SEG + 1) <= K / GS_SEG + T.  (A capacity that could run
-        // out would make WHICH lists get cuts depend on the order of the claims, and with it the last bits of the gradients.)
+        // every long list has its records at start / GS_SEG + tile (k_blend_fwd.hip): K / GS_SEG + T + 1 of them hold all lists'.  (Nothing
+        // is claimed at run time: a capacity that could run out would make WHICH lists get cuts, and with it the last bits of the
+        // gradients, depend on the order of the claims.)
         cut_cap = (int)std::min<uint64_t>((uint64_t)K_bound / GS_SEG + (uint64_t)T + 2, 0x7fffffffu);
         ENSURE(B.cuts, (size_t)cut_cap * 256 * sizeof(float4)); ENSURE(B.cut_mag, (size_t)cut_cap * 256 * sizeof(float2));
     }

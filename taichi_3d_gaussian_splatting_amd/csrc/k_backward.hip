@@ -47,7 +47,9 @@
 // ten to twenty times the mean and their single waves ARE the launch (profiles/r03_*_wave_timeline*.txt); on the uniform
 // generator (max / mean = 2) there are none.  Which tiles are heavy changes the ORDER in which a pair's contributions are added
 // (quadrant sums, then their sum), hence the set is whole bins of the histogram: a deterministic function of the work counts.
-#define HEAVY_MIN_WORK 1024
+#ifndef HEAVY_MIN_WORK
+#define HEAVY_MIN_WORK 512       // (1024 until the lists over 512 entries were cut: cfg2_clustered backward 0.180 -> 0.164 ms, nothing elsewhere; 256: the same)
+#endif
 #define HEAVY_CAP GS_HEAVY_CAP
 __host__ __device__ inline int gs_heavy_cap(int T) { return T / 8 < HEAVY_CAP ? T / 8 : HEAVY_CAP; }
 // A heavy tile whose list the forward CUT (k_blend_fwd: every GS_SEG entries each pixel's T and the colour since the last cut) is handed out
