@@ -630,6 +630,9 @@ def test_predicted_sizing_and_its_redo_change_nothing(P):
     whose pair count outgrew the prediction (the scene doubles between two frames) and a frame whose depth codes got wider
     (depth_to_sort_key_scale x 64) must all give, bit for bit, what a fresh context gives with exact sizes -- forward outputs,
     every exported intermediate, gradients."""
+    import os
+    if os.environ.get("GS_PREDICT_SIZES") == "0":
+        pytest.skip("the library's diagnostic switch GS_PREDICT_SIZES=0 turns the mechanism under test off")
     q, t = view_pose()
     small, big = synth(6000, 256, 192, 0.05, seed=41), synth(12000, 256, 192, 0.07, seed=42)
 
